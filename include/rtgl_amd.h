@@ -1,0 +1,134 @@
+/*
+ * rtgl_amd.h -- C ABI of the MI355X-native progressive path tracer (drop-in boundary).
+ *
+ * The reference (gue-ni/raytracer.glsl) has no plugin / FFI layer: its hot path sits behind the
+ * C++ class `Renderer : public Window` (reference src/renderer.h:127-148) and the OpenGL driver.
+ * This header is the flat C boundary a maintainer binds instead of the GL calls; the C++ facade
+ * in include/rtgl/renderer.h (same class names and method signatures as the reference) is a thin
+ * layer over exactly these entry points.  Each entry point cites the reference interface it
+ * replaces.  Plain pointers and sizes only; every call returns 0 on success or a negative
+ * rtgl_status, with text available from rtgl_last_error().
+ *
+ * Threading (reference: single-threaded, everything on the thread that owns the GL context,
+ * src/window.cpp:13): one host thread per context; calls on one context must not overlap.
+ * Ownership (reference: setters copy synchronously via glBufferData, src/gfx/gl.h:93-97): every
+ * upload copies; the caller may free its buffer as soon as the call returns.
+ */
+#ifndef RTGL_AMD_H
+#define RTGL_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rtgl_context rtgl_context;
+
+typedef enum rtgl_status {
+    RTGL_OK = 0,
+    RTGL_ERR_INVALID = -1,   /* bad argument */
+    RTGL_ERR_DEVICE = -2,    /* HIP runtime error (text in rtgl_last_error) */
+    RTGL_ERR_NO_DEVICE = -3, /* no usable gfx950 device: the library has no CPU fallback */
+    RTGL_ERR_STATE = -4      /* call not valid in the current state */
+} rtgl_status;
+
+/* The 17 uniforms of reference shaders/raytracer.glsl:62-81, set per frame by
+ * src/renderer.cpp:96-123 (glUniform* by name).  camera_fov is in radians (renderer.cpp:116).
+ * `time` is uploaded by the reference but never read by the shader; kept for symmetry. */
+typedef struct rtgl_frame_params {
+    int32_t  frames;       /* u_frames  = Window::m_frames after the pre-render increment (window.cpp:42) */
+    uint32_t samples;      /* u_samples (renderer.h:168: always 1 in the reference) */
+    uint32_t max_bounce;   /* u_max_bounce */
+    float    time;         /* u_time (dead) */
+    float    background[3];
+    int32_t  reset_flag;   /* u_reset_flag */
+    int32_t  use_envmap;   /* u_use_envmap (false when no cube map is set, renderer.cpp:104-110) */
+    int32_t  use_dof;      /* u_use_dof */
+    int32_t  random;       /* u_random = rand() once per frame (renderer.cpp:102) */
+    float    camera_position[3];
+    float    camera_fov;
+    float    camera_aperture;
+    float    camera_focal_length;
+    float    camera_forward[3];
+    float    camera_up[3];
+    float    camera_right[3];
+} rtgl_frame_params;
+
+/* Device-side work counters of the last rendered frame (no reference counterpart; feeds the
+ * Msegments/s and Gtests/s figures of SURVEY.md 8(d1)). */
+typedef struct rtgl_counters {
+    uint64_t paths;          /* pixel-samples started */
+    uint64_t segments;       /* bounce iterations executed */
+    uint64_t triangle_tests; /* ray x triangle edge-function evaluations */
+    uint64_t candidates;     /* tests that reached the exact (reference-order) re-evaluation */
+    uint64_t env_lookups;
+    uint64_t reserved[3];
+} rtgl_counters;
+
+/* Kernel variants (rtgl_set_option "kernel").  All produce bit-identical images. */
+enum { RTGL_KERNEL_MEGA = 0, RTGL_KERNEL_WAVEFRONT = 1 };
+
+/* -- lifetime: replaces Renderer::Renderer(width,height) GL object creation (src/renderer.cpp:21-64).
+ * The accumulation image is RGBA32F, width x height, zero-initialised (the reference leaves it
+ * undefined).  device = HIP device ordinal. */
+int rtgl_create(rtgl_context **out, int width, int height, int device);
+
+/* Same, but this context owns only the row strips s with (s % world) == rank, where strip s covers
+ * image rows [s*strip_rows, (s+1)*strip_rows).  Pixel seeds and camera rays use absolute pixel
+ * coordinates, so the union over ranks is bit-identical to a single-context render.  strip_rows
+ * must be a multiple of 8.  (No reference counterpart: SURVEY.md 8(e).) */
+int rtgl_create_tiled(rtgl_context **out, int width, int height, int device, int rank, int world, int strip_rows);
+
+void rtgl_destroy(rtgl_context *ctx);
+const char *rtgl_last_error(const rtgl_context *ctx); /* ctx may be NULL: error of the last failed create */
+
+/* -- scene upload: replaces the set_* family (src/renderer.cpp:151-216), layouts per the shader's
+ * buffer declarations (shaders/raytracer.glsl:11-60).  count = number of elements. */
+int rtgl_upload_spheres(rtgl_context *ctx, const void *spheres, uint32_t count);     /* 32 B each; set_spheres :151-155 */
+int rtgl_upload_materials(rtgl_context *ctx, const void *materials, uint32_t count); /* 32 B each; set_materials :157-161 */
+int rtgl_upload_meshes(rtgl_context *ctx, const void *meshes, uint32_t count);       /* 16 B each; set_meshes :181-185 */
+int rtgl_upload_vertices(rtgl_context *ctx, const void *vec4s, uint32_t vec4_count); /* 16 B each, 3 per triangle; set_vertices :174-179 */
+int rtgl_upload_nodes(rtgl_context *ctx, const void *nodes, uint32_t count);         /* 48 B each; set_nodes :187-191 */
+/* faces: 6 (or fewer) tightly packed 8-bit images in +X,-X,+Y,-Y,+Z,-Z order, channels 3 or 4;
+ * replaces CubemapTexture's constructor (src/gfx/gl.cpp:241-260) + set_envmap (renderer.cpp:163-172).
+ * nfaces < 6 reproduces the incomplete cube of a failed face load (lookups return black). */
+int rtgl_upload_envmap(rtgl_context *ctx, const uint8_t *faces, int nfaces, int width, int height, int channels);
+
+/* -- per frame: replaces the uniform uploads + glDispatchCompute + glMemoryBarrier of
+ * Renderer::render (src/renderer.cpp:96-134).  rtgl_render_frame enqueues on the context's stream
+ * and returns; rtgl_synchronize waits. */
+int rtgl_set_frame_params(rtgl_context *ctx, const rtgl_frame_params *params);
+int rtgl_render_frame(rtgl_context *ctx);
+int rtgl_synchronize(rtgl_context *ctx);
+
+/* -- image access: replaces glGetTexImage in save_to_file (src/renderer.cpp:218-223).
+ * f32: RGBA32F rows bottom-up exactly as stored (row 0 = pixel y 0).  For a tiled context the
+ * buffer holds only the local strips, packed in increasing strip order (rtgl_local_rows rows).
+ * u8: clamp to [0,1], scale by 255, round to nearest (what GL_UNSIGNED_BYTE readback does);
+ * flip != 0 writes the top row first like stbi_write_png's flipped output (renderer.cpp:240). */
+int rtgl_read_image_f32(rtgl_context *ctx, float *rgba);
+int rtgl_read_image_u8(rtgl_context *ctx, uint8_t *rgba, int flip);
+int rtgl_write_image_f32(rtgl_context *ctx, const float *rgba); /* preload / resume the accumulation image */
+int rtgl_clear_image(rtgl_context *ctx);
+int rtgl_local_rows(const rtgl_context *ctx);      /* rows held by this context (== height when not tiled) */
+int rtgl_local_row_to_global(const rtgl_context *ctx, int local_row);
+
+/* -- plumbing for callers that own device memory / streams (PyTorch, RCCL) */
+void *rtgl_device_image(rtgl_context *ctx);                 /* device pointer of the local RGBA32F buffer */
+int rtgl_bind_device_image(rtgl_context *ctx, void *dptr);  /* render into caller-owned device memory (local_rows*width*16 B) */
+int rtgl_set_stream(rtgl_context *ctx, void *hip_stream);   /* hipStream_t; NULL restores the context's own stream */
+
+/* -- diagnostics */
+int rtgl_get_counters(rtgl_context *ctx, rtgl_counters *out);  /* synchronises */
+int rtgl_read_rng_state(rtgl_context *ctx, uint32_t *xyzw);    /* per local pixel final PCG4D state of the last frame; needs option "rng_state"=1 */
+int rtgl_set_option(rtgl_context *ctx, const char *key, int value); /* "kernel", "rng_state", "counters" */
+int rtgl_get_option(rtgl_context *ctx, const char *key, int *value);
+/* elapsed GPU milliseconds of the last rtgl_render_frame (HIP events on the context's stream) */
+int rtgl_last_frame_ms(rtgl_context *ctx, float *ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RTGL_AMD_H */

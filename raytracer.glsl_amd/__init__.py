@@ -1,5 +1,6 @@
 """MI355X-native progressive path tracer: HIP kernels + C ABI (csrc/), the host-side mirror of the
 reference's Renderer/Window interface (include/, host.py) and the synthetic scene generators."""
 from . import scenes  # noqa: F401
+from . import host  # noqa: F401
 
-__all__ = ["scenes"]
+__all__ = ["scenes", "host"]

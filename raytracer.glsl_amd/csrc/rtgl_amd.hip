@@ -1,0 +1,594 @@
+// rtgl_amd.hip -- HIP kernels + C ABI (include/rtgl_amd.h) of the MI355X-native path tracer.
+// gfx950 only.  Build: see raytracer.glsl_amd/csrc/Makefile (hipcc --offload-arch=gfx950
+// -ffp-contract=off).  There is no CPU fallback: without a HIP device every entry point fails.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/rtgl_amd.h"
+#include "rt_device.hpp"
+
+#pragma clang fp contract(off)
+
+using namespace rt;
+
+// =================================================================================================
+// Kernels
+// =================================================================================================
+
+// ---- upload-time preparation -------------------------------------------------------------------
+// One thread per triangle visit.  visit_tri[k] = triangle index tested k-th by the reference's
+// mesh loops (find_closest_mesh :336-341: meshes in order, triangles start..start+size-1 each).
+__global__ void __launch_bounds__(256) prepare_triangles_kernel(const float4 *__restrict__ vertices,
+                                                                const uint32_t *__restrict__ visit_tri, uint32_t n_visits,
+                                                                TriEdges *__restrict__ edges, TriPlane *__restrict__ planes)
+{
+    uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_visits) return;
+    uint32_t tri = visit_tri[k];
+    float4 a = vertices[3 * (size_t)tri + 0], b = vertices[3 * (size_t)tri + 1], c = vertices[3 * (size_t)tri + 2];
+    f3 v0 = mk(a.x, a.y, a.z), v1 = mk(b.x, b.y, b.z), v2 = mk(c.x, c.y, c.z);
+    f3 e0 = v1 - v0, e1 = v2 - v1, e2 = v0 - v2;                                   // :230,233,236
+    f3 m0 = cross3(v1, v0), m1 = cross3(v2, v1), m2 = cross3(v0, v2);              // :231,234,237
+    f3 n = normalize3(cross3(v1 - v0, v2 - v0));                                   // :239
+    TriEdges E;
+    E.e0x = e0.x; E.e0y = e0.y; E.e0z = e0.z; E.e1x = e1.x; E.e1y = e1.y; E.e1z = e1.z; E.e2x = e2.x; E.e2y = e2.y; E.e2z = e2.z;
+    E.m0x = m0.x; E.m0y = m0.y; E.m0z = m0.z; E.m1x = m1.x; E.m1y = m1.y; E.m1z = m1.z; E.m2x = m2.x; E.m2y = m2.y; E.m2z = m2.z;
+    float be = fmaxf(fmaxf(dot3(e0, e0), dot3(e1, e1)), dot3(e2, e2));
+    float bm = fmaxf(fmaxf(dot3(m0, m0), dot3(m1, m1)), dot3(m2, m2));
+    E.bound_e = __builtin_sqrtf(be) * 1.0001f;
+    E.bound_m = __builtin_sqrtf(bm) * 1.0001f;
+    edges[k] = E;
+    TriPlane P;
+    P.nx = n.x; P.ny = n.y; P.nz = n.z; P.v0x = v0.x; P.v0y = v0.y; P.v0z = v0.z;
+    float w = a.w;                                                                 // int(vertices[3v].w) :353
+    P.material = (w > -2147483648.0f && w < 2147483648.0f) ? (int32_t)w : -1;
+    P.pad = 0;
+    planes[k] = P;
+}
+
+// ---- shared per-pixel pieces ---------------------------------------------------------------------
+struct ImageView {
+    float4 *pixels;     // local RGBA32F rows
+    int width, height;  // full image size
+    int disp_w, disp_h; // dispatch footprint: width/8*8, height/8*8 (src/renderer.cpp:132-133)
+    int local_rows;
+    int rank, world, strip_rows;   // row-strip ownership (world == 1: everything)
+};
+
+__device__ __forceinline__ int local_to_global_row(const ImageView &im, int lr)
+{
+    if (im.world == 1) return lr;
+    int ls = lr / im.strip_rows, within = lr - ls * im.strip_rows;
+    return (ls * im.world + im.rank) * im.strip_rows + within;
+}
+
+struct Counters { unsigned long long paths, segments, tri_tests, candidates, env_lookups; };
+
+// running mean of main() (:561-568)
+__device__ __forceinline__ float4 accumulate_pixel(const FrameParams &P, f3 color, f3 prev)
+{
+    float ns = (float)P.samples;
+    color = mk(color.x / ns, color.y / ns, color.z / ns);
+    float fr = (float)P.frames, fr1 = (float)(P.frames + 1);
+    return make_float4((color.x + prev.x * fr) / fr1, (color.y + prev.y * fr) / fr1, (color.z + prev.z * fr) / fr1, 1.0f);
+}
+
+// ---- variant 0: megakernel, one lane per pixel ----------------------------------------------------
+// Triangle records are wave-uniform, so the compiler fetches them with scalar loads (SGPR operands
+// feed the fma chain directly); no LDS traffic.  Baseline variant, kept as the A/B reference for the
+// tiled / wavefront kernels.
+template <bool kCount>
+__global__ void __launch_bounds__(256) pathtrace_mega_kernel(SceneView sc, FrameParams P, ImageView im, uint4 *rng_out, Counters *counters)
+{
+    // 8x8 pixel block per wave (matches the reference work-group shape :38), 4 waves side by side
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int px = (blockIdx.x * 4 + wave) * 8 + (lane & 7);
+    const int lrow = blockIdx.y * 8 + (lane >> 3);
+    if (px >= im.disp_w || lrow >= im.local_rows) return;
+    const int py = local_to_global_row(im, lrow);
+    if (py >= im.disp_h) return;
+
+    Rng rng; rng.x = (uint32_t)px; rng.y = (uint32_t)py; rng.z = (uint32_t)P.random;       // init_rand :135-138
+    rng.w = (uint32_t)px + (uint32_t)py + (uint32_t)P.random;
+    float4 *pix = im.pixels + (size_t)lrow * im.width + px;
+    f3 prev = mk(0.0f, 0.0f, 0.0f);
+    if (!P.reset_flag) { float4 q = *pix; prev = mk(q.x, q.y, q.z); }                       // :542-548
+    f3 origin, dir;
+    camera_ray(P, px, py, im.width, im.height, rng, origin, dir);
+
+    unsigned long long c_seg = 0, c_tests = 0, c_cand = 0, c_env = 0;
+    f3 color = mk(0.0f, 0.0f, 0.0f);
+    for (uint32_t s = 0; s < P.samples; ++s) {                                              // :556-559
+        f3 o = origin, d = dir;
+        f3 radiance = mk(0.0f, 0.0f, 0.0f), thr = mk(1.0f, 1.0f, 1.0f);
+        for (uint32_t bounce = 0; bounce < P.max_bounce; ++bounce) {                        // :425
+            if (kCount) c_seg++;
+            Hit h1; h1.t = kInf; h1.material = 0; h1.point = h1.normal = mk(0.0f, 0.0f, 0.0f);
+            bool hit_sphere = sphere_pass(sc, o, d, h1);                                    // :433
+            // find_closest_mesh (:331-361)
+            TriRay tr = make_tri_ray(o, d);
+            float best_t = kInf; uint32_t best_v = 0xFFFFFFFFu;
+            for (uint32_t v = 0; v < sc.n_tri_visits; ++v) {
+                const TriEdges &T = sc.tri_edges[v];
+                if (tri_filter(T, tr)) {
+                    if (kCount) c_cand++;
+                    float t = tri_exact(T, sc.tri_planes[v], tr);
+                    if (kEps < t && t < best_t) { best_t = t; best_v = v; }
+                }
+            }
+            if (kCount) c_tests += sc.n_tri_visits;
+            bool hit_mesh = best_v != 0xFFFFFFFFu;
+            if (!hit_sphere && !hit_mesh) {                                                 // :441-445
+                f3 bg;
+                if (P.use_envmap) { bg = env_lookup(sc, d); if (kCount) c_env++; }
+                else bg = mk(P.background[0], P.background[1], P.background[2]);
+                radiance = radiance + bg * thr;
+                break;
+            }
+            Hit h = h1;
+            if (!(h1.t < best_t)) {                                                         // :447
+                const TriPlane &pl = sc.tri_planes[best_v];
+                h.t = best_t; h.point = o + d * best_t; h.normal = mk(pl.nx, pl.ny, pl.nz); h.material = pl.material;
+            }
+            if (!shade_hit(sc, h, rng, o, d, thr, radiance)) break;
+        }
+        color = color + radiance;
+    }
+    *pix = accumulate_pixel(P, color, prev);
+    if (rng_out) rng_out[(size_t)lrow * im.width + px] = make_uint4(rng.x, rng.y, rng.z, rng.w);
+    if (kCount) {
+        atomicAdd(&counters->paths, (unsigned long long)P.samples);
+        atomicAdd(&counters->segments, c_seg);
+        atomicAdd(&counters->tri_tests, c_tests);
+        atomicAdd(&counters->candidates, c_cand);
+        atomicAdd(&counters->env_lookups, c_env);
+    }
+}
+
+// ---- 8-bit readback (glGetTexImage GL_UNSIGNED_BYTE, src/renderer.cpp:223) -----------------------
+__global__ void __launch_bounds__(256) image_to_u8_kernel(const float4 *__restrict__ src, uchar4 *__restrict__ dst, int width, int rows, int flip)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= width * rows) return;
+    int y = i / width, x = i - y * width;
+    float4 p = src[i];
+    auto q = [](float v) -> unsigned char {
+        v = v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v);      // NaN -> 0 like a clamp-to-[0,1] conversion
+        if (!(v == v)) v = 0.0f;
+        return (unsigned char)__builtin_rintf(v * 255.0f);
+    };
+    int oy = flip ? rows - 1 - y : y;
+    dst[(size_t)oy * width + x] = make_uchar4(q(p.x), q(p.y), q(p.z), q(p.w));
+}
+
+// =================================================================================================
+// Host side: context + C ABI
+// =================================================================================================
+
+static thread_local std::string g_create_error;
+
+struct rtgl_context {
+    int device = 0;
+    int width = 0, height = 0;
+    int rank = 0, world = 1, strip_rows = 8, local_rows = 0;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timed = false;
+    std::string error;
+
+    // raw scene copies (host) used to rebuild derived buffers
+    std::vector<uint8_t> h_meshes, h_nodes;
+    uint32_t n_meshes = 0, n_nodes = 0, n_vec4 = 0;
+
+    // device buffers
+    SphereRec *d_spheres = nullptr; uint32_t n_spheres = 0;
+    MaterialRec *d_materials = nullptr; uint32_t n_materials = 0;
+    float4 *d_vertices = nullptr;
+    uint32_t *d_sphere_visits = nullptr; uint32_t n_sphere_visits = 0;
+    TriEdges *d_edges = nullptr; TriPlane *d_planes = nullptr; uint32_t n_tri_visits = 0;
+    uint8_t *d_env = nullptr; int env_w = 0, env_h = 0, env_c = 0, env_faces = 0;
+    float4 *d_image_own = nullptr, *d_image = nullptr;
+    uint4 *d_rng = nullptr;
+    Counters *d_counters = nullptr;
+    uchar4 *d_u8 = nullptr;
+
+    bool tris_dirty = false, visits_dirty = false;
+    FrameParams params{};
+    bool have_params = false;
+    int opt_kernel = RTGL_KERNEL_MEGA, opt_rng_state = 0, opt_counters = 0;
+};
+
+static int fail(rtgl_context *ctx, int code, const std::string &msg)
+{
+    if (ctx) ctx->error = msg; else g_create_error = msg;
+    return code;
+}
+#define HIPCHK(ctx, expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) \
+    return fail(ctx, RTGL_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); } while (0)
+
+template <typename T>
+static int realloc_upload(rtgl_context *ctx, T *&dptr, const void *src, size_t bytes)
+{
+    if (dptr) { HIPCHK(ctx, hipFree(dptr)); dptr = nullptr; }
+    if (bytes == 0) return RTGL_OK;
+    HIPCHK(ctx, hipMalloc((void **)&dptr, bytes));
+    if (src) HIPCHK(ctx, hipMemcpyAsync(dptr, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));   // uploads are synchronous like glBufferData
+    return RTGL_OK;
+}
+
+static int local_rows_for(int height, int rank, int world, int strip_rows)
+{
+    int n_strips = (height + strip_rows - 1) / strip_rows, rows = 0;
+    for (int s = rank; s < n_strips; s += world) rows += std::min(strip_rows, height - s * strip_rows);
+    return rows;
+}
+
+extern "C" int rtgl_create_tiled(rtgl_context **out, int width, int height, int device, int rank, int world, int strip_rows)
+{
+    if (!out) return fail(nullptr, RTGL_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    if (width <= 0 || height <= 0 || world < 1 || rank < 0 || rank >= world || strip_rows <= 0 || (strip_rows % 8) != 0)
+        return fail(nullptr, RTGL_ERR_INVALID, "rtgl_create: bad size / tiling arguments");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(nullptr, RTGL_ERR_NO_DEVICE, "no HIP device visible (this library has no CPU path)");
+    if (device < 0 || device >= ndev) return fail(nullptr, RTGL_ERR_INVALID, "device ordinal out of range");
+    rtgl_context *ctx = new rtgl_context();
+    ctx->device = device; ctx->width = width; ctx->height = height;
+    ctx->rank = rank; ctx->world = world; ctx->strip_rows = strip_rows;
+    ctx->local_rows = local_rows_for(height, rank, world, strip_rows);
+    auto bail = [&](int code) { g_create_error = ctx->error; rtgl_destroy(ctx); return code; };
+#define CCHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { \
+    ctx->error = std::string(#expr) + ": " + hipGetErrorString(e_); return bail(RTGL_ERR_DEVICE); } } while (0)
+    CCHK(hipSetDevice(device));
+    CCHK(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
+    ctx->stream = ctx->own_stream;
+    CCHK(hipEventCreate(&ctx->ev0));
+    CCHK(hipEventCreate(&ctx->ev1));
+    size_t img_bytes = (size_t)std::max(ctx->local_rows, 1) * width * sizeof(float4);
+    CCHK(hipMalloc((void **)&ctx->d_image_own, img_bytes));
+    CCHK(hipMemsetAsync(ctx->d_image_own, 0, img_bytes, ctx->stream));
+    ctx->d_image = ctx->d_image_own;
+    CCHK(hipMalloc((void **)&ctx->d_counters, sizeof(Counters)));
+    CCHK(hipMemsetAsync(ctx->d_counters, 0, sizeof(Counters), ctx->stream));
+    CCHK(hipStreamSynchronize(ctx->stream));
+#undef CCHK
+    *out = ctx;
+    return RTGL_OK;
+}
+
+extern "C" int rtgl_create(rtgl_context **out, int width, int height, int device)
+{
+    return rtgl_create_tiled(out, width, height, device, 0, 1, 8);
+}
+
+extern "C" void rtgl_destroy(rtgl_context *ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    void *ptrs[] = { ctx->d_spheres, ctx->d_materials, ctx->d_vertices, ctx->d_sphere_visits, ctx->d_edges, ctx->d_planes,
+                     ctx->d_env, ctx->d_image_own, ctx->d_rng, ctx->d_counters, ctx->d_u8 };
+    for (void *p : ptrs) if (p) (void)hipFree(p);
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+}
+
+extern "C" const char *rtgl_last_error(const rtgl_context *ctx) { return ctx ? ctx->error.c_str() : g_create_error.c_str(); }
+
+#define ENTER(ctx) do { if (!(ctx)) return RTGL_ERR_INVALID; HIPCHK(ctx, hipSetDevice((ctx)->device)); } while (0)
+
+extern "C" int rtgl_upload_spheres(rtgl_context *ctx, const void *data, uint32_t count)
+{
+    ENTER(ctx);
+    if (count && !data) return fail(ctx, RTGL_ERR_INVALID, "spheres is NULL");
+    static_assert(sizeof(SphereRec) == 32, "Sphere stride (shaders/raytracer.glsl:11-15, std140)");
+    int rc = realloc_upload(ctx, ctx->d_spheres, data, (size_t)count * 32);
+    if (rc) return rc;
+    ctx->n_spheres = count; ctx->visits_dirty = true;
+    return RTGL_OK;
+}
+
+extern "C" int rtgl_upload_materials(rtgl_context *ctx, const void *data, uint32_t count)
+{
+    ENTER(ctx);
+    if (count && !data) return fail(ctx, RTGL_ERR_INVALID, "materials is NULL");
+    static_assert(sizeof(MaterialRec) == 32, "Material stride (shaders/raytracer.glsl:17-21, std140)");
+    int rc = realloc_upload(ctx, ctx->d_materials, data, (size_t)count * 32);
+    if (rc) return rc;
+    ctx->n_materials = count;
+    return RTGL_OK;
+}
+
+extern "C" int rtgl_upload_meshes(rtgl_context *ctx, const void *data, uint32_t count)
+{
+    ENTER(ctx);
+    if (count && !data) return fail(ctx, RTGL_ERR_INVALID, "meshes is NULL");
+    ctx->h_meshes.assign((const uint8_t *)data, (const uint8_t *)data + (size_t)count * 16);
+    ctx->n_meshes = count; ctx->tris_dirty = true;
+    return RTGL_OK;
+}
+
+extern "C" int rtgl_upload_vertices(rtgl_context *ctx, const void *data, uint32_t vec4_count)
+{
+    ENTER(ctx);
+    if (vec4_count && !data) return fail(ctx, RTGL_ERR_INVALID, "vertices is NULL");
+    int rc = realloc_upload(ctx, ctx->d_vertices, data, (size_t)vec4_count * 16);
+    if (rc) return rc;
+    ctx->n_vec4 = vec4_count; ctx->tris_dirty = true;
+    return RTGL_OK;
+}
+
+extern "C" int rtgl_upload_nodes(rtgl_context *ctx, const void *data, uint32_t count)
+{
+    ENTER(ctx);
+    if (count && !data) return fail(ctx, RTGL_ERR_INVALID, "nodes is NULL");
+    ctx->h_nodes.assign((const uint8_t *)data, (const uint8_t *)data + (size_t)count * 48);
+    ctx->n_nodes = count; ctx->visits_dirty = true;
+    return RTGL_OK;
+}
+
+extern "C" int rtgl_upload_envmap(rtgl_context *ctx, const uint8_t *faces, int nfaces, int width, int height, int channels)
+{
+    ENTER(ctx);
+    if (nfaces < 0 || nfaces > 6 || width <= 0 || height <= 0 || (channels != 3 && channels != 4) || (nfaces && !faces))
+        return fail(ctx, RTGL_ERR_INVALID, "envmap: need 0..6 faces, positive size, 3 or 4 channels");
+    int rc = realloc_upload(ctx, ctx->d_env, faces, (size_t)nfaces * width * height * channels);
+    if (rc) return rc;
+    ctx->env_w = width; ctx->env_h = height; ctx->env_c = channels; ctx->env_faces = nfaces;
+    return RTGL_OK;
+}
+
+// traverse() (:272-329) walks the node buffer identically for every ray; run that walk once here and
+// keep the sphere indices in test order.  Stack of 5 with silently dropped pushes (:113-121), nodes
+// outside the buffer are childless and empty, walk capped at 65535 pops.
+static int rebuild_sphere_visits(rtgl_context *ctx)
+{
+    std::vector<uint32_t> visits;
+    const size_t kMaxVisits = 1u << 20;
+    if (ctx->n_nodes > 0) {
+        uint32_t items[5] = { 0, 0, 0, 0, 0 };
+        int top = 0, pops = 0;
+        auto rd = [&](uint32_t node, int off) { uint32_t v; memcpy(&v, ctx->h_nodes.data() + (size_t)node * 48 + off, 4); return v; };
+        while (top != -1 && pops < 65535) {
+            uint32_t id = items[top--];
+            pops++;
+            uint32_t left = 0xFFFFFFFFu, right = 0xFFFFFFFFu, offset = 0, count = 0;
+            if (id < ctx->n_nodes) { left = rd(id, 32); right = rd(id, 36); offset = rd(id, 40); count = rd(id, 44); }
+            if (left != 0xFFFFFFFFu && top != 4) items[++top] = left;
+            if (right != 0xFFFFFFFFu && top != 4) items[++top] = right;
+            uint64_t end = (uint64_t)offset + count;
+            bool zero_emitted = false;
+            for (uint64_t i = offset; i < end; ++i) {
+                if (i < ctx->n_spheres) visits.push_back((uint32_t)i);
+                else {   // every out-of-range index reads the same all-zero sphere: one visit stands for the run
+                    if (!zero_emitted) visits.push_back(kNoSphere);
+                    zero_emitted = true;
+                    break;
+                }
+                if (visits.size() > kMaxVisits) return fail(ctx, RTGL_ERR_INVALID, "node buffer expands to more than 2^20 sphere tests per ray");
+            }
+        }
+    }
+    int rc = realloc_upload(ctx, ctx->d_sphere_visits, visits.data(), visits.size() * sizeof(uint32_t));
+    if (rc) return rc;
+    ctx->n_sphere_visits = (uint32_t)visits.size();
+    ctx->visits_dirty = false;
+    return RTGL_OK;
+}
+
+static int rebuild_triangles(rtgl_context *ctx)
+{
+    std::vector<uint32_t> visit_tri;
+    uint32_t n_tris = ctx->n_vec4 / 3;   // to_triangles() drops a trailing partial triangle (src/renderer.h:34-48)
+    for (uint32_t m = 0; m < ctx->n_meshes; ++m) {
+        uint32_t start, size;
+        memcpy(&start, ctx->h_meshes.data() + (size_t)m * 16, 4);
+        memcpy(&size, ctx->h_meshes.data() + (size_t)m * 16 + 4, 4);
+        uint64_t end = std::min<uint64_t>((uint64_t)start + size, n_tris);
+        for (uint64_t t = start; t < end; ++t) visit_tri.push_back((uint32_t)t);
+    }
+    if (ctx->d_edges) { HIPCHK(ctx, hipFree(ctx->d_edges)); ctx->d_edges = nullptr; }
+    if (ctx->d_planes) { HIPCHK(ctx, hipFree(ctx->d_planes)); ctx->d_planes = nullptr; }
+    ctx->n_tri_visits = (uint32_t)visit_tri.size();
+    if (ctx->n_tri_visits) {
+        uint32_t *d_visit = nullptr;
+        HIPCHK(ctx, hipMalloc((void **)&d_visit, visit_tri.size() * 4));
+        HIPCHK(ctx, hipMemcpyAsync(d_visit, visit_tri.data(), visit_tri.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(ctx, hipMalloc((void **)&ctx->d_edges, (size_t)ctx->n_tri_visits * sizeof(TriEdges)));
+        HIPCHK(ctx, hipMalloc((void **)&ctx->d_planes, (size_t)ctx->n_tri_visits * sizeof(TriPlane)));
+        dim3 grid((ctx->n_tri_visits + 255) / 256);
+        hipLaunchKernelGGL(prepare_triangles_kernel, grid, dim3(256), 0, ctx->stream, ctx->d_vertices, d_visit, ctx->n_tri_visits, ctx->d_edges, ctx->d_planes);
+        HIPCHK(ctx, hipGetLastError());
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        HIPCHK(ctx, hipFree(d_visit));
+    }
+    ctx->tris_dirty = false;
+    return RTGL_OK;
+}
+
+extern "C" int rtgl_set_frame_params(rtgl_context *ctx, const rtgl_frame_params *p)
+{
+    ENTER(ctx);
+    if (!p) return fail(ctx, RTGL_ERR_INVALID, "params is NULL");
+    static_assert(sizeof(FrameParams) == sizeof(rtgl_frame_params), "FrameParams mirrors rtgl_frame_params");
+    memcpy(&ctx->params, p, sizeof(FrameParams));
+    ctx->have_params = true;
+    return RTGL_OK;
+}
+
+extern "C" int rtgl_render_frame(rtgl_context *ctx)
+{
+    ENTER(ctx);
+    if (!ctx->have_params) return fail(ctx, RTGL_ERR_STATE, "rtgl_set_frame_params has not been called");
+    if (ctx->params.samples == 0) return fail(ctx, RTGL_ERR_INVALID, "u_samples == 0 divides by zero in the reference; refused");
+    if (ctx->visits_dirty) { int rc = rebuild_sphere_visits(ctx); if (rc) return rc; }
+    if (ctx->tris_dirty) { int rc = rebuild_triangles(ctx); if (rc) return rc; }
+    if (ctx->opt_rng_state && !ctx->d_rng)
+        HIPCHK(ctx, hipMalloc((void **)&ctx->d_rng, (size_t)std::max(ctx->local_rows, 1) * ctx->width * sizeof(uint4)));
+
+    SceneView sc{};
+    sc.spheres = ctx->d_spheres; sc.n_spheres = ctx->n_spheres;
+    sc.sphere_visits = ctx->d_sphere_visits; sc.n_sphere_visits = ctx->n_sphere_visits;
+    sc.materials = ctx->d_materials; sc.n_materials = ctx->n_materials;
+    sc.tri_edges = ctx->d_edges; sc.tri_planes = ctx->d_planes; sc.n_tri_visits = ctx->n_tri_visits;
+    sc.env = ctx->d_env; sc.env_w = ctx->env_w; sc.env_h = ctx->env_h; sc.env_c = ctx->env_c; sc.env_faces = ctx->env_faces;
+    FrameParams P = ctx->params;
+    if (!ctx->d_env) P.use_envmap = 0;   // src/renderer.cpp:104-110: no cube map => u_use_envmap = false
+    ImageView im{};
+    im.pixels = ctx->d_image; im.width = ctx->width; im.height = ctx->height;
+    im.disp_w = ctx->width / 8 * 8; im.disp_h = ctx->height / 8 * 8;
+    im.local_rows = ctx->local_rows; im.rank = ctx->rank; im.world = ctx->world; im.strip_rows = ctx->strip_rows;
+
+    if (ctx->opt_counters) HIPCHK(ctx, hipMemsetAsync(ctx->d_counters, 0, sizeof(Counters), ctx->stream));
+    HIPCHK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+    if (im.disp_w > 0 && ctx->local_rows > 0) {
+        dim3 grid((im.disp_w + 31) / 32, (ctx->local_rows + 7) / 8);
+        uint4 *rng_out = ctx->opt_rng_state ? ctx->d_rng : nullptr;
+        if (ctx->opt_counters)
+            hipLaunchKernelGGL(pathtrace_mega_kernel<true>, grid, dim3(256), 0, ctx->stream, sc, P, im, rng_out, ctx->d_counters);
+        else
+            hipLaunchKernelGGL(pathtrace_mega_kernel<false>, grid, dim3(256), 0, ctx->stream, sc, P, im, rng_out, ctx->d_counters);
+        HIPCHK(ctx, hipGetLastError());
+    }
+    HIPCHK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+    ctx->timed = true;
+    return RTGL_OK;
+}
+
+extern "C" int rtgl_synchronize(rtgl_context *ctx)
+{
+    ENTER(ctx);
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return RTGL_OK;
+}
+
+extern "C" int rtgl_last_frame_ms(rtgl_context *ctx, float *ms)
+{
+    ENTER(ctx);
+    if (!ms || !ctx->timed) return fail(ctx, RTGL_ERR_STATE, "no frame has been rendered");
+    HIPCHK(ctx, hipEventSynchronize(ctx->ev1));
+    HIPCHK(ctx, hipEventElapsedTime(ms, ctx->ev0, ctx->ev1));
+    return RTGL_OK;
+}
+
+extern "C" int rtgl_read_image_f32(rtgl_context *ctx, float *rgba)
+{
+    ENTER(ctx);
+    if (!rgba) return fail(ctx, RTGL_ERR_INVALID, "rgba is NULL");
+    HIPCHK(ctx, hipMemcpyAsync(rgba, ctx->d_image, (size_t)ctx->local_rows * ctx->width * 16, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return RTGL_OK;
+}
+
+extern "C" int rtgl_write_image_f32(rtgl_context *ctx, const float *rgba)
+{
+    ENTER(ctx);
+    if (!rgba) return fail(ctx, RTGL_ERR_INVALID, "rgba is NULL");
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_image, rgba, (size_t)ctx->local_rows * ctx->width * 16, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return RTGL_OK;
+}
+
+extern "C" int rtgl_clear_image(rtgl_context *ctx)
+{
+    ENTER(ctx);
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_image, 0, (size_t)ctx->local_rows * ctx->width * 16, ctx->stream));
+    return RTGL_OK;
+}
+
+extern "C" int rtgl_read_image_u8(rtgl_context *ctx, uint8_t *rgba, int flip)
+{
+    ENTER(ctx);
+    if (!rgba) return fail(ctx, RTGL_ERR_INVALID, "rgba is NULL");
+    size_t n = (size_t)ctx->local_rows * ctx->width;
+    if (n == 0) return RTGL_OK;
+    if (!ctx->d_u8) HIPCHK(ctx, hipMalloc((void **)&ctx->d_u8, n * 4));
+    hipLaunchKernelGGL(image_to_u8_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
+                       ctx->d_image, ctx->d_u8, ctx->width, ctx->local_rows, flip);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipMemcpyAsync(rgba, ctx->d_u8, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return RTGL_OK;
+}
+
+extern "C" int rtgl_local_rows(const rtgl_context *ctx) { return ctx ? ctx->local_rows : RTGL_ERR_INVALID; }
+
+extern "C" int rtgl_local_row_to_global(const rtgl_context *ctx, int lr)
+{
+    if (!ctx || lr < 0 || lr >= ctx->local_rows) return RTGL_ERR_INVALID;
+    if (ctx->world == 1) return lr;
+    int ls = lr / ctx->strip_rows, within = lr - ls * ctx->strip_rows;
+    return (ls * ctx->world + ctx->rank) * ctx->strip_rows + within;
+}
+
+extern "C" void *rtgl_device_image(rtgl_context *ctx) { return ctx ? (void *)ctx->d_image : nullptr; }
+
+extern "C" int rtgl_bind_device_image(rtgl_context *ctx, void *dptr)
+{
+    ENTER(ctx);
+    ctx->d_image = dptr ? (float4 *)dptr : ctx->d_image_own;
+    return RTGL_OK;
+}
+
+extern "C" int rtgl_set_stream(rtgl_context *ctx, void *hip_stream)
+{
+    ENTER(ctx);
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    return RTGL_OK;
+}
+
+extern "C" int rtgl_get_counters(rtgl_context *ctx, rtgl_counters *out)
+{
+    ENTER(ctx);
+    if (!out) return fail(ctx, RTGL_ERR_INVALID, "out is NULL");
+    Counters c;
+    HIPCHK(ctx, hipMemcpyAsync(&c, ctx->d_counters, sizeof c, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    memset(out, 0, sizeof *out);
+    out->paths = c.paths; out->segments = c.segments; out->triangle_tests = c.tri_tests;
+    out->candidates = c.candidates; out->env_lookups = c.env_lookups;
+    return RTGL_OK;
+}
+
+extern "C" int rtgl_read_rng_state(rtgl_context *ctx, uint32_t *xyzw)
+{
+    ENTER(ctx);
+    if (!xyzw) return fail(ctx, RTGL_ERR_INVALID, "xyzw is NULL");
+    if (!ctx->opt_rng_state || !ctx->d_rng) return fail(ctx, RTGL_ERR_STATE, "option rng_state was not enabled before rendering");
+    HIPCHK(ctx, hipMemcpyAsync(xyzw, ctx->d_rng, (size_t)ctx->local_rows * ctx->width * 16, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return RTGL_OK;
+}
+
+extern "C" int rtgl_set_option(rtgl_context *ctx, const char *key, int value)
+{
+    ENTER(ctx);
+    if (!key) return fail(ctx, RTGL_ERR_INVALID, "key is NULL");
+    if (!strcmp(key, "kernel")) {
+        if (value != RTGL_KERNEL_MEGA) return fail(ctx, RTGL_ERR_INVALID, "unknown kernel variant");
+        ctx->opt_kernel = value;
+    } else if (!strcmp(key, "rng_state")) ctx->opt_rng_state = value != 0;
+    else if (!strcmp(key, "counters")) ctx->opt_counters = value != 0;
+    else return fail(ctx, RTGL_ERR_INVALID, std::string("unknown option ") + key);
+    return RTGL_OK;
+}
+
+extern "C" int rtgl_get_option(rtgl_context *ctx, const char *key, int *value)
+{
+    ENTER(ctx);
+    if (!key || !value) return fail(ctx, RTGL_ERR_INVALID, "NULL argument");
+    if (!strcmp(key, "kernel")) *value = ctx->opt_kernel;
+    else if (!strcmp(key, "rng_state")) *value = ctx->opt_rng_state;
+    else if (!strcmp(key, "counters")) *value = ctx->opt_counters;
+    else return fail(ctx, RTGL_ERR_INVALID, std::string("unknown option ") + key);
+    return RTGL_OK;
+}
