@@ -1,0 +1,190 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Mpaths/s on the C2 workload of BASELINE.json (1920x1080, 8 bounces,
+10,000-triangle mesh + spheres + cube map), progressive frames on N MI355X of one node.
+
+    python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
+
+A "step" is one frame: one pass of the per-pixel path-trace hot path over the whole image (1 sample
+per pixel) including the running-mean accumulation and, for N>1, the frame-end gather of the tile
+buffers to rank 0 over RCCL.  Scene, cube map and the accumulation image are resident in HBM before
+the timed region starts.  One JSON line is printed by rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+FP32_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: peak FP32 vector
+
+
+def scene_bytes(scene) -> int:
+    """S_scene of SURVEY.md 8(d3): reference-layout bytes one pass over the scene reads."""
+    return (48 * scene.n_triangles + 32 * scene.spheres.shape[0] + 48 * scene.nodes.shape[0]
+            + 32 * scene.materials.shape[0])
+
+
+def algorithmic_bytes(width, height, counters, scene, reset=False) -> float:
+    """image read+write (32 B/px, 16 on a reset frame) + one scene stream per
+    256-ray group per bounce pass (segments/256 groups with perfect compaction) + 16 B per
+    environment lookup (four RGBA8 texels)."""
+    px = (width // 8 * 8) * (height // 8 * 8)
+    return px * (16 if reset else 32) + (counters["segments"] / 256.0) * scene_bytes(scene) + 16.0 * counters["env_lookups"]
+
+
+def cpu_baseline(rt, scene, params, width, height, budget_rows=256):
+    """The oracle (C restatement, oracle/pathtrace_oracle.c) timed on this host's cores over a
+    bounded, uniformly strided sample of the same frame: strips of 8 rows every `stride` rows."""
+    from oracle.oracle import CpuOracle
+    import numpy as np
+    orc = CpuOracle()
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    dh = height // 8 * 8
+    n_strips = max(1, budget_rows // 8)
+    stride = max(8, (dh // n_strips) // 8 * 8)
+    img = np.zeros((height, width, 4), np.float32)
+    pixels = 0
+    t0 = time.perf_counter()
+    for y0 in range(0, dh, stride):
+        orc.render(scene, params, img, rect=(0, y0, width // 8 * 8, min(y0 + 8, dh)), threads=cores)
+        pixels += (width // 8 * 8) * (min(y0 + 8, dh) - y0)
+    dt = time.perf_counter() - t0
+    return {
+        "value": pixels * params.samples / dt / 1e6, "unit": "Mpaths/s", "cores": cores, "kind": "port",
+        "sample": f"one frame, 8-row strips every {stride} rows = {pixels} of {(width // 8 * 8) * dh} pixels, {dt:.1f} s",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="C2", help="C2 (headline), C4, C5 or C1")
+    ap.add_argument("--kernel", type=int, default=None, help="kernel variant override (rtgl_set_option kernel)")
+    ap.add_argument("--wf-rays", type=int, default=None, help="rays per lane of the wavefront kernel (1, 2, 4)")
+    ap.add_argument("--wf-mode", type=int, default=None, help="triangle operand path: 0 scalar loads, 1 LDS tiles")
+    ap.add_argument("--strip-rows", type=int, default=16)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-rows", type=int, default=256)
+    args = ap.parse_args()
+
+    import torch
+    import raytracer_glsl_amd as rt
+    sc = rt.scenes
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)   # nccl == RCCL on ROCm
+
+    cfg = sc.CONFIGS[args.config]
+    W, H = cfg["width"], cfg["height"]
+    scene = cfg["scene"]()
+    base = cfg["params"]()
+
+    ctx = rt.host.Context(W, H, device=local_rank, rank=rank, world=world, strip_rows=args.strip_rows)
+    ctx.upload_scene(scene)
+    for key, val in (("kernel", args.kernel), ("wf_rays", args.wf_rays), ("wf_mode", args.wf_mode)):
+        if val is not None:
+            ctx.set_option(key, val)
+    gat = rt.tiling.FrameGatherer(W, H, rank, world, dev, args.strip_rows)
+    ctx.bind_device_image(gat.local.data_ptr())          # render straight into the buffer the gather sends
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+
+    rnd = sc.GlibcRand(0)
+    frame_no = [0]
+
+    def next_params():
+        frame_no[0] += 1
+        return base.replace(frames=frame_no[0], random=rnd.rand())
+
+    def step(p):
+        ctx.render(p, sync=False)
+        gat.gather()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step(next_params())
+    timed = [next_params() for _ in range(args.steps)]
+    kernel_ms = 0.0
+    barrier()
+    t0 = time.perf_counter()
+    for p in timed:
+        step(p)
+        kernel_ms += ctx.last_frame_ms()                  # HIP events on the launch stream (syncs that frame)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    # untimed: work counters of one representative frame (atomics are off in the timed region)
+    ctx.set_option("counters", 1)
+    ctx.render(timed[0].replace(frames=frame_no[0] + 1), sync=True)
+    cnt = ctx.counters()
+    ctx.set_option("counters", 0)
+    if world > 1:
+        ct = torch.tensor([cnt["segments"], cnt["triangle_tests"], cnt["env_lookups"], cnt["paths"], cnt["candidates"]],
+                          dtype=torch.float64, device=dev)
+        dist.all_reduce(ct, op=dist.ReduceOp.SUM)
+        cnt = dict(segments=int(ct[0]), triangle_tests=int(ct[1]), env_lookups=int(ct[2]), paths=int(ct[3]), candidates=int(ct[4]))
+
+    if rank == 0:
+        px = (W // 8 * 8) * (H // 8 * 8)
+        paths = px * base.samples * args.steps
+        avg_kernel_s = kernel_ms / 1e3 / args.steps       # rank 0's launches
+        # per-launch algorithmic bytes of rank 0's launch = its share of the frame
+        share = 1.0 / world
+        alg_bytes = algorithmic_bytes(W, H, cnt, scene) * share
+        alg_flops = cnt["triangle_tests"] * 36.0 * share   # 18 fma per ray-triangle edge evaluation
+        out = {
+            "metric": "Mpaths/s at 1920x1080, 8 bounces, 10k tris" if args.config == "C2" else f"Mpaths/s ({args.config})",
+            "value": paths / dt / 1e6, "unit": "Mpaths/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.config}: {W}x{H}, {base.max_bounce} bounces, {scene.n_triangles} triangles + "
+                                   f"{scene.spheres.shape[0]} spheres, cube map {scene.env.shape[1] if scene.env is not None else 0}^2, "
+                                   f"1 spp/frame progressive, dof={base.use_dof}",
+                       "parallelism": f"{world} GPU(s), {args.strip_rows}-row strips interleaved, gather to rank 0 every frame",
+                       "kernel": ctx.get_option("kernel"), "wf_rays": ctx.get_option("wf_rays"), "wf_mode": ctx.get_option("wf_mode")},
+            "roofline": {"bound": "hbm", "achieved": alg_bytes / avg_kernel_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": alg_bytes / avg_kernel_s / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "pathtrace (per-frame launch)", "avg_launch_ms": avg_kernel_s * 1e3,
+                         "algorithmic_bytes_per_launch": alg_bytes},
+            "valu": {"achieved": alg_flops / avg_kernel_s / 1e12, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": alg_flops / avg_kernel_s / 1e12 / FP32_PEAK_TFLOPS,
+                     "gtests_per_s": cnt["triangle_tests"] * share / avg_kernel_s / 1e9},
+            "counters_per_frame": cnt,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(rt, scene, timed[0], W, H, args.cpu_rows)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -508,10 +508,14 @@ static void *worker(void *arg)
 {
     job_t *jb = (job_t *)arg;
     oracle_counters c; memset(&c, 0, sizeof c);
+    const int w = jb->x1 - jb->x0, h = jb->y1 - jb->y0;
+    const int chunks_per_row = (w + 63) / 64, n_chunks = chunks_per_row * (h > 0 ? h : 0);
     for (;;) {
-        int y = __sync_fetch_and_add(&jb->next_row, 1);
-        if (y >= jb->y1) break;
-        for (int x = jb->x0; x < jb->x1; x++)
+        int k = __sync_fetch_and_add(&jb->next_row, 1);   /* work item = 64 consecutive pixels of one row */
+        if (k >= n_chunks) break;
+        int y = jb->y0 + k / chunks_per_row, xa = jb->x0 + (k % chunks_per_row) * 64;
+        int xb = xa + 64 < jb->x1 ? xa + 64 : jb->x1;
+        for (int x = xa; x < xb; x++)
             render_pixel(jb->sc, jb->P, jb->W, jb->H, x, y, jb->image, jb->seed_out, &c);
     }
     pthread_mutex_lock(&jb->mu);
@@ -531,7 +535,7 @@ int oracle_render(const oracle_scene *sc, const oracle_params *P, int W, int H, 
     job_t jb;
     memset(&jb, 0, sizeof jb);
     jb.sc = sc; jb.P = P; jb.W = W; jb.H = H; jb.x0 = x0; jb.y0 = y0; jb.x1 = x1; jb.y1 = y1;
-    jb.image = image; jb.seed_out = seed_out; jb.next_row = y0;
+    jb.image = image; jb.seed_out = seed_out; jb.next_row = 0;
     pthread_mutex_init(&jb.mu, NULL);
     if (nthreads < 1) nthreads = 1;
     if (nthreads > 256) nthreads = 256;

@@ -389,4 +389,31 @@ __device__ __forceinline__ bool shade_hit(const SceneView &sc, const Hit &h, Rng
     return true;
 }
 
+// ---- image addressing, counters, running mean ---------------------------------------------------
+struct ImageView {
+    float4 *pixels;     // local RGBA32F rows
+    int width, height;  // full image size
+    int disp_w, disp_h; // dispatch footprint: width/8*8, height/8*8 (src/renderer.cpp:132-133)
+    int local_rows;
+    int rank, world, strip_rows;   // row-strip ownership (world == 1: everything)
+};
+
+__device__ __forceinline__ int local_to_global_row(const ImageView &im, int lr)
+{
+    if (im.world == 1) return lr;
+    int ls = lr / im.strip_rows, within = lr - ls * im.strip_rows;
+    return (ls * im.world + im.rank) * im.strip_rows + within;
+}
+
+struct Counters { unsigned long long paths, segments, tri_tests, candidates, env_lookups; };
+
+// running mean of main() (:561-568)
+__device__ __forceinline__ float4 accumulate_pixel(const FrameParams &P, f3 color, f3 prev)
+{
+    float ns = (float)P.samples;
+    color = mk(color.x / ns, color.y / ns, color.z / ns);
+    float fr = (float)P.frames, fr1 = (float)(P.frames + 1);
+    return make_float4((color.x + prev.x * fr) / fr1, (color.y + prev.y * fr) / fr1, (color.z + prev.z * fr) / fr1, 1.0f);
+}
+
 }  // namespace rt

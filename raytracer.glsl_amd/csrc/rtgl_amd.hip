@@ -10,6 +10,7 @@
 
 #include "../../include/rtgl_amd.h"
 #include "rt_device.hpp"
+#include "rt_wavefront.hpp"
 
 #pragma clang fp contract(off)
 
@@ -48,33 +49,6 @@ __global__ void __launch_bounds__(256) prepare_triangles_kernel(const float4 *__
     P.material = (w > -2147483648.0f && w < 2147483648.0f) ? (int32_t)w : -1;
     P.pad = 0;
     planes[k] = P;
-}
-
-// ---- shared per-pixel pieces ---------------------------------------------------------------------
-struct ImageView {
-    float4 *pixels;     // local RGBA32F rows
-    int width, height;  // full image size
-    int disp_w, disp_h; // dispatch footprint: width/8*8, height/8*8 (src/renderer.cpp:132-133)
-    int local_rows;
-    int rank, world, strip_rows;   // row-strip ownership (world == 1: everything)
-};
-
-__device__ __forceinline__ int local_to_global_row(const ImageView &im, int lr)
-{
-    if (im.world == 1) return lr;
-    int ls = lr / im.strip_rows, within = lr - ls * im.strip_rows;
-    return (ls * im.world + im.rank) * im.strip_rows + within;
-}
-
-struct Counters { unsigned long long paths, segments, tri_tests, candidates, env_lookups; };
-
-// running mean of main() (:561-568)
-__device__ __forceinline__ float4 accumulate_pixel(const FrameParams &P, f3 color, f3 prev)
-{
-    float ns = (float)P.samples;
-    color = mk(color.x / ns, color.y / ns, color.z / ns);
-    float fr = (float)P.frames, fr1 = (float)(P.frames + 1);
-    return make_float4((color.x + prev.x * fr) / fr1, (color.y + prev.y * fr) / fr1, (color.z + prev.z * fr) / fr1, 1.0f);
 }
 
 // ---- variant 0: megakernel, one lane per pixel ----------------------------------------------------
@@ -196,10 +170,16 @@ struct rtgl_context {
     Counters *d_counters = nullptr;
     uchar4 *d_u8 = nullptr;
 
+    // bounce-wavefront pipeline buffers
+    float2 *d_group_bounds = nullptr;
+    void *d_wave = nullptr; size_t wave_capacity = 0; bool wave_multi = false;   // queues (+ per-pixel state when u_samples > 1)
+    uint32_t *d_counts = nullptr; uint32_t counts_capacity = 0;
+    WaveBuffers wb{};
+
     bool tris_dirty = false, visits_dirty = false;
     FrameParams params{};
     bool have_params = false;
-    int opt_kernel = RTGL_KERNEL_MEGA, opt_rng_state = 0, opt_counters = 0;
+    int opt_kernel = RTGL_KERNEL_WAVEFRONT, opt_rng_state = 0, opt_counters = 0, opt_wf_rays = 2, opt_wf_mode = kLds;
 };
 
 static int fail(rtgl_context *ctx, int code, const std::string &msg)
@@ -273,7 +253,7 @@ extern "C" void rtgl_destroy(rtgl_context *ctx)
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     void *ptrs[] = { ctx->d_spheres, ctx->d_materials, ctx->d_vertices, ctx->d_sphere_visits, ctx->d_edges, ctx->d_planes,
-                     ctx->d_env, ctx->d_image_own, ctx->d_rng, ctx->d_counters, ctx->d_u8 };
+                     ctx->d_env, ctx->d_image_own, ctx->d_rng, ctx->d_counters, ctx->d_u8, ctx->d_group_bounds, ctx->d_wave, ctx->d_counts };
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -407,10 +387,89 @@ static int rebuild_triangles(rtgl_context *ctx)
         dim3 grid((ctx->n_tri_visits + 255) / 256);
         hipLaunchKernelGGL(prepare_triangles_kernel, grid, dim3(256), 0, ctx->stream, ctx->d_vertices, d_visit, ctx->n_tri_visits, ctx->d_edges, ctx->d_planes);
         HIPCHK(ctx, hipGetLastError());
+        if (ctx->d_group_bounds) { HIPCHK(ctx, hipFree(ctx->d_group_bounds)); ctx->d_group_bounds = nullptr; }
+        uint32_t n_groups = (ctx->n_tri_visits + kBoundGroup - 1) / kBoundGroup;
+        HIPCHK(ctx, hipMalloc((void **)&ctx->d_group_bounds, (size_t)n_groups * sizeof(float2)));
+        hipLaunchKernelGGL(group_bounds_kernel, dim3(n_groups), dim3(64), 0, ctx->stream, ctx->d_edges, ctx->n_tri_visits, ctx->d_group_bounds);
+        HIPCHK(ctx, hipGetLastError());
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
         HIPCHK(ctx, hipFree(d_visit));
     }
     ctx->tris_dirty = false;
+    return RTGL_OK;
+}
+
+// ---- bounce-wavefront pipeline: buffers + launches ------------------------------------------------
+static int ensure_wave_buffers(rtgl_context *ctx, uint32_t n0, uint32_t max_bounce, bool multi_sample)
+{
+    if (ctx->counts_capacity < max_bounce + 2) {
+        if (ctx->d_counts) { HIPCHK(ctx, hipFree(ctx->d_counts)); ctx->d_counts = nullptr; }
+        HIPCHK(ctx, hipMalloc((void **)&ctx->d_counts, (size_t)(max_bounce + 2) * sizeof(uint32_t)));
+        ctx->counts_capacity = max_bounce + 2;
+    }
+    const size_t local_px = (size_t)std::max(ctx->local_rows, 1) * ctx->width;
+    if (ctx->wave_capacity < n0 || (multi_sample && !ctx->wave_multi)) {
+        if (ctx->d_wave) { HIPCHK(ctx, hipFree(ctx->d_wave)); ctx->d_wave = nullptr; }
+        // per queue: 4 x 16 B + 4 B per ray; per-pixel state for u_samples > 1: 4 x 16 B
+        size_t q_bytes = (size_t)n0 * 68, bytes = 2 * q_bytes + 256 + (multi_sample ? local_px * 64 : 0);
+        HIPCHK(ctx, hipMalloc(&ctx->d_wave, bytes));
+        ctx->wave_capacity = n0; ctx->wave_multi = multi_sample;
+        uint8_t *p = (uint8_t *)ctx->d_wave;
+        for (int q = 0; q < 2; ++q) {
+            ctx->wb.q[q].a = (float4 *)p; p += (size_t)n0 * 16;
+            ctx->wb.q[q].b = (float4 *)p; p += (size_t)n0 * 16;
+            ctx->wb.q[q].c = (float4 *)p; p += (size_t)n0 * 16;
+            ctx->wb.q[q].rng = (uint4 *)p; p += (size_t)n0 * 16;
+        }
+        for (int q = 0; q < 2; ++q) { ctx->wb.q[q].pixel = (uint32_t *)p; p += (size_t)n0 * 4; }
+        p = (uint8_t *)(((uintptr_t)p + 255) & ~(uintptr_t)255);
+        if (multi_sample) {
+            ctx->wb.sums = (float4 *)p; p += local_px * 16;
+            ctx->wb.cam_a = (float4 *)p; p += local_px * 16;
+            ctx->wb.cam_b = (float4 *)p; p += local_px * 16;
+            ctx->wb.pix_rng = (uint4 *)p; p += local_px * 16;
+        } else ctx->wb.sums = ctx->wb.cam_a = ctx->wb.cam_b = nullptr, ctx->wb.pix_rng = nullptr;
+    }
+    ctx->wb.counts = ctx->d_counts;
+    ctx->wb.group_bounds = ctx->d_group_bounds;
+    return RTGL_OK;
+}
+
+template <int R, int MODE>
+static void launch_bounce(rtgl_context *ctx, const SceneView &sc, const FrameParams &P, const ImageView &im, uint32_t n0, uint32_t bounce, uint4 *rng_out)
+{
+    dim3 grid((n0 + 256u * R - 1) / (256u * R));
+    if (ctx->opt_counters)
+        hipLaunchKernelGGL((bounce_kernel<R, MODE, true>), grid, dim3(256), 0, ctx->stream, sc, P, im, ctx->wb, bounce, rng_out, ctx->d_counters);
+    else
+        hipLaunchKernelGGL((bounce_kernel<R, MODE, false>), grid, dim3(256), 0, ctx->stream, sc, P, im, ctx->wb, bounce, rng_out, ctx->d_counters);
+}
+
+static int launch_wavefront(rtgl_context *ctx, const SceneView &sc, const FrameParams &P, const ImageView &im, uint32_t n0, uint4 *rng_out)
+{
+    const dim3 gen_grid((n0 + 255) / 256);
+    for (uint32_t s = 0; s < P.samples; ++s) {
+        HIPCHK(ctx, hipMemsetAsync(ctx->d_counts, 0, (size_t)(P.max_bounce + 2) * sizeof(uint32_t), ctx->stream));
+        hipLaunchKernelGGL(generate_rays_kernel, gen_grid, dim3(256), 0, ctx->stream, P, im, ctx->wb, s, n0,
+                           ctx->opt_counters ? ctx->d_counters : (Counters *)nullptr);
+        for (uint32_t b = 0; b < P.max_bounce; ++b) {
+            const int key = ctx->opt_wf_mode * 10 + ctx->opt_wf_rays;
+            switch (key) {
+            case 1: launch_bounce<1, kScalar>(ctx, sc, P, im, n0, b, rng_out); break;
+            case 2: launch_bounce<2, kScalar>(ctx, sc, P, im, n0, b, rng_out); break;
+            case 4: launch_bounce<4, kScalar>(ctx, sc, P, im, n0, b, rng_out); break;
+            case 11: launch_bounce<1, kLds>(ctx, sc, P, im, n0, b, rng_out); break;
+            case 12: launch_bounce<2, kLds>(ctx, sc, P, im, n0, b, rng_out); break;
+            case 14: launch_bounce<4, kLds>(ctx, sc, P, im, n0, b, rng_out); break;
+            default: return fail(ctx, RTGL_ERR_STATE, "unsupported wf_mode / wf_rays combination");
+            }
+        }
+        HIPCHK(ctx, hipGetLastError());
+    }
+    if (P.samples > 1u) {
+        hipLaunchKernelGGL(resolve_kernel, gen_grid, dim3(256), 0, ctx->stream, P, im, ctx->wb);
+        HIPCHK(ctx, hipGetLastError());
+    }
     return RTGL_OK;
 }
 
@@ -448,15 +507,24 @@ extern "C" int rtgl_render_frame(rtgl_context *ctx)
     im.local_rows = ctx->local_rows; im.rank = ctx->rank; im.world = ctx->world; im.strip_rows = ctx->strip_rows;
 
     if (ctx->opt_counters) HIPCHK(ctx, hipMemsetAsync(ctx->d_counters, 0, sizeof(Counters), ctx->stream));
+    // rows of the dispatch footprint held locally: a prefix of the local rows (strips are 8-row aligned)
+    int local_disp_rows = 0;
+    for (int lr = 0; lr < ctx->local_rows; ++lr) if (rtgl_local_row_to_global(ctx, lr) < im.disp_h) local_disp_rows = lr + 1;
+    const uint32_t n0 = (uint32_t)im.disp_w * (uint32_t)local_disp_rows;
+    uint4 *rng_out = ctx->opt_rng_state ? ctx->d_rng : nullptr;
+    const bool use_wavefront = ctx->opt_kernel == RTGL_KERNEL_WAVEFRONT && P.max_bounce > 0;
+    if (use_wavefront && n0 > 0) { int rc = ensure_wave_buffers(ctx, n0, P.max_bounce, P.samples > 1); if (rc) return rc; }
     HIPCHK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
-    if (im.disp_w > 0 && ctx->local_rows > 0) {
-        dim3 grid((im.disp_w + 31) / 32, (ctx->local_rows + 7) / 8);
-        uint4 *rng_out = ctx->opt_rng_state ? ctx->d_rng : nullptr;
+    if (n0 > 0 && !use_wavefront) {
+        dim3 grid((im.disp_w + 31) / 32, (local_disp_rows + 7) / 8);
         if (ctx->opt_counters)
             hipLaunchKernelGGL(pathtrace_mega_kernel<true>, grid, dim3(256), 0, ctx->stream, sc, P, im, rng_out, ctx->d_counters);
         else
             hipLaunchKernelGGL(pathtrace_mega_kernel<false>, grid, dim3(256), 0, ctx->stream, sc, P, im, rng_out, ctx->d_counters);
         HIPCHK(ctx, hipGetLastError());
+    } else if (n0 > 0) {
+        int rc = launch_wavefront(ctx, sc, P, im, n0, rng_out);
+        if (rc) return rc;
     }
     HIPCHK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
     ctx->timed = true;
@@ -574,8 +642,14 @@ extern "C" int rtgl_set_option(rtgl_context *ctx, const char *key, int value)
     ENTER(ctx);
     if (!key) return fail(ctx, RTGL_ERR_INVALID, "key is NULL");
     if (!strcmp(key, "kernel")) {
-        if (value != RTGL_KERNEL_MEGA) return fail(ctx, RTGL_ERR_INVALID, "unknown kernel variant");
+        if (value != RTGL_KERNEL_MEGA && value != RTGL_KERNEL_WAVEFRONT) return fail(ctx, RTGL_ERR_INVALID, "unknown kernel variant");
         ctx->opt_kernel = value;
+    } else if (!strcmp(key, "wf_rays")) {
+        if (value != 1 && value != 2 && value != 4) return fail(ctx, RTGL_ERR_INVALID, "wf_rays must be 1, 2 or 4");
+        ctx->opt_wf_rays = value;
+    } else if (!strcmp(key, "wf_mode")) {
+        if (value != kScalar && value != kLds) return fail(ctx, RTGL_ERR_INVALID, "wf_mode must be 0 (scalar) or 1 (lds)");
+        ctx->opt_wf_mode = value;
     } else if (!strcmp(key, "rng_state")) ctx->opt_rng_state = value != 0;
     else if (!strcmp(key, "counters")) ctx->opt_counters = value != 0;
     else return fail(ctx, RTGL_ERR_INVALID, std::string("unknown option ") + key);
@@ -587,6 +661,8 @@ extern "C" int rtgl_get_option(rtgl_context *ctx, const char *key, int *value)
     ENTER(ctx);
     if (!key || !value) return fail(ctx, RTGL_ERR_INVALID, "NULL argument");
     if (!strcmp(key, "kernel")) *value = ctx->opt_kernel;
+    else if (!strcmp(key, "wf_rays")) *value = ctx->opt_wf_rays;
+    else if (!strcmp(key, "wf_mode")) *value = ctx->opt_wf_mode;
     else if (!strcmp(key, "rng_state")) *value = ctx->opt_rng_state;
     else if (!strcmp(key, "counters")) *value = ctx->opt_counters;
     else return fail(ctx, RTGL_ERR_INVALID, std::string("unknown option ") + key);

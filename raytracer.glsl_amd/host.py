@@ -225,6 +225,11 @@ class Context:
     def set_option(self, key: str, value: int):
         self._chk(self.lib.rtgl_set_option(self.h, key.encode(), int(value)))
 
+    def get_option(self, key: str) -> int:
+        v = C.c_int()
+        self._chk(self.lib.rtgl_get_option(self.h, key.encode(), C.byref(v)))
+        return int(v.value)
+
     def counters(self) -> dict:
         c = CCounters()
         self._chk(self.lib.rtgl_get_counters(self.h, C.byref(c)))

@@ -6,10 +6,16 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def run_both(rt, oracle, scene, params, W, H, frames=1, rng_state=True, reset_at=None):
+# (kernel, wf_mode, wf_rays): megakernel, wavefront with scalar-fed / LDS-tiled triangle pass
+VARIANTS = [(0, 0, 1), (1, 0, 1), (1, 0, 2), (1, 0, 4), (1, 1, 1), (1, 1, 2), (1, 1, 4)]
+
+
+def run_both(rt, oracle, scene, params, W, H, frames=1, rng_state=True, reset_at=None, variant=None):
     sc = rt.scenes
     ctx = rt.host.Context(W, H)
     ctx.upload_scene(scene)
+    if variant is not None:
+        ctx.set_option("kernel", variant[0]); ctx.set_option("wf_mode", variant[1]); ctx.set_option("wf_rays", variant[2])
     if rng_state:
         ctx.set_option("rng_state", 1)
     ctx.set_option("counters", 1)
@@ -40,6 +46,21 @@ def assert_bit_exact(r, W, H):
     assert r["cnt_g"]["segments"] == r["cnt_o"]["segments"]
     assert r["cnt_g"]["paths"] == r["cnt_o"]["paths"]
     assert r["cnt_g"]["env_lookups"] == r["cnt_o"]["env_lookups"]
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_variants_mesh_env(rt, oracle, variant):
+    sc = rt.scenes
+    r = run_both(rt, oracle, sc.scene_mesh(30, 10, env_size=32), sc.params_c2(), 136, 72, frames=2, variant=variant)
+    assert_bit_exact(r, 136, 72)
+    assert r["cnt_g"]["triangle_tests"] == r["cnt_o"]["triangle_tests"]
+
+
+@pytest.mark.parametrize("variant", [(0, 0, 1), (1, 1, 2), (1, 0, 4)])
+def test_two_samples_per_frame(rt, oracle, variant):
+    sc = rt.scenes
+    r = run_both(rt, oracle, sc.scene_mesh(20, 10, env_size=16), sc.params_c2().replace(samples=2), 64, 64, frames=2, variant=variant)
+    assert_bit_exact(r, 64, 64)
 
 
 def test_c1_spheres(rt, oracle):
