@@ -68,7 +68,11 @@ typedef struct rtgl_counters {
 } rtgl_counters;
 
 /* Kernel variants (rtgl_set_option "kernel").  All produce bit-identical images. */
-enum { RTGL_KERNEL_MEGA = 0, RTGL_KERNEL_WAVEFRONT = 1 };
+enum {
+    RTGL_KERNEL_MEGA = 0,            /* one launch per frame, one lane per pixel, whole path in registers */
+    RTGL_KERNEL_WAVEFRONT = 1,       /* one fused launch per bounce over the compacted ray queue */
+    RTGL_KERNEL_WAVEFRONT_SPLIT = 2  /* per bounce: intersect (ray blocks x triangle chunks) + shade; default */
+};
 
 /* -- lifetime: replaces Renderer::Renderer(width,height) GL object creation (src/renderer.cpp:21-64).
  * The accumulation image is RGBA32F, width x height, zero-initialised (the reference leaves it
@@ -123,7 +127,9 @@ int rtgl_set_stream(rtgl_context *ctx, void *hip_stream);   /* hipStream_t; NULL
 /* -- diagnostics */
 int rtgl_get_counters(rtgl_context *ctx, rtgl_counters *out);  /* synchronises */
 int rtgl_read_rng_state(rtgl_context *ctx, uint32_t *xyzw);    /* per local pixel final PCG4D state of the last frame; needs option "rng_state"=1 */
-int rtgl_set_option(rtgl_context *ctx, const char *key, int value); /* "kernel", "rng_state", "counters" */
+/* keys: "kernel" (enum above), "wf_rays" (rays per lane 1/2/4/8), "wf_mode" (0 scalar-fed, 1 LDS tiles),
+ * "wf_chunk" (triangles per work item of the split intersect kernel, multiple of 64), "rng_state", "counters" */
+int rtgl_set_option(rtgl_context *ctx, const char *key, int value);
 int rtgl_get_option(rtgl_context *ctx, const char *key, int *value);
 /* elapsed GPU milliseconds of the last rtgl_render_frame (HIP events on the context's stream) */
 int rtgl_last_frame_ms(rtgl_context *ctx, float *ms);

@@ -43,6 +43,7 @@ struct WaveBuffers {
     float4 *cam_a, *cam_b;// per local pixel camera ray (only u_samples > 1)
     uint4 *pix_rng;       // per local pixel RNG state between samples (only u_samples > 1)
     const float2 *group_bounds;   // per kBoundGroup triangles: (max bound_e, max bound_m)
+    unsigned long long *best[2];  // split pipeline: per queue slot, packed (t bits << 32 | visit index) of the nearest mesh hit
 };
 
 struct PathState { f3 o, d, thr, rad; Rng rng; uint32_t pixel; };
@@ -122,6 +123,7 @@ __global__ void __launch_bounds__(256) generate_rays_kernel(FrameParams P, Image
     }
     s.thr = mk(1.0f, 1.0f, 1.0f); s.rad = mk(0.0f, 0.0f, 0.0f);
     store_ray(wb.q[0], idx, s);
+    if (wb.best[0]) wb.best[0][idx] = 0xFFFFFFFFFFFFFFFFull;
 }
 
 __global__ void __launch_bounds__(256) resolve_kernel(FrameParams P, ImageView im, WaveBuffers wb)
@@ -140,49 +142,72 @@ __global__ void __launch_bounds__(256) resolve_kernel(FrameParams P, ImageView i
 }
 
 // ---- one bounce --------------------------------------------------------------------------------------
+// Register discipline: during the triangle pass a ray is only (cv, d, margin scales, threshold,
+// best t, best index) = 11 VGPRs; origin, throughput, radiance, RNG state and pixel stay in the
+// queue in HBM and are (re)loaded after the pass.  The exact re-test of a candidate (rare) fetches
+// what it needs from memory instead of keeping it live.
 template <int R>
-struct RayRegs {           // the hot-loop view of R rays
-    TriRay tr[R];
-    float ncv[R], nd[R];   // margin scales (-inf marks an empty slot)
+struct HotRays {
+    f3 cv[R], d[R];        // cross(d, o), d
+    float ncv[R], nd[R];   // margin scales (-inf marks an empty slot: its threshold becomes +inf)
     float thresh[R];       // -margin for the current bound group
     float best_t[R];
     uint32_t best_v[R];
 };
 
 template <int R>
-__device__ __forceinline__ void set_thresh(RayRegs<R> &rr, float2 gb)
+__device__ __forceinline__ void set_thresh(HotRays<R> &hr, float2 gb)
 {
 #pragma unroll
-    for (int r = 0; r < R; ++r) rr.thresh[r] = -(__builtin_fmaf(gb.x, rr.ncv[r], gb.y * rr.nd[r]) + 1e-30f);
+    for (int r = 0; r < R; ++r) hr.thresh[r] = -(__builtin_fmaf(gb.x, hr.ncv[r], gb.y * hr.nd[r]) + 1e-30f);
 }
 
-// filter value of one triangle for one ray: min over the three edge functions (see tri_filter)
-__device__ __forceinline__ float tri_filter_min(const TriEdges &T, const TriRay &r)
+// the 18 edge-function coefficients of one triangle as they sit in a TriEdges record
+struct TriCoef { float4 q0, q1, q2, q3; float2 q4; };
+// q0 = e0x e0y e0z e1x | q1 = e1y e1z e2x e2y | q2 = e2z m0x m0y m0z | q3 = m1x m1y m1z m2x | q4 = m2y m2z
+
+__device__ __forceinline__ float filter_min(const TriCoef &T, f3 cv, f3 d)
 {
-    float f0 = T.e0x * r.cv.x;
-    f0 = __builtin_fmaf(T.e0y, r.cv.y, f0); f0 = __builtin_fmaf(T.e0z, r.cv.z, f0);
-    f0 = __builtin_fmaf(T.m0x, r.d.x, f0); f0 = __builtin_fmaf(T.m0y, r.d.y, f0); f0 = __builtin_fmaf(T.m0z, r.d.z, f0);
-    float f1 = T.e1x * r.cv.x;
-    f1 = __builtin_fmaf(T.e1y, r.cv.y, f1); f1 = __builtin_fmaf(T.e1z, r.cv.z, f1);
-    f1 = __builtin_fmaf(T.m1x, r.d.x, f1); f1 = __builtin_fmaf(T.m1y, r.d.y, f1); f1 = __builtin_fmaf(T.m1z, r.d.z, f1);
-    float f2 = T.e2x * r.cv.x;
-    f2 = __builtin_fmaf(T.e2y, r.cv.y, f2); f2 = __builtin_fmaf(T.e2z, r.cv.z, f2);
-    f2 = __builtin_fmaf(T.m2x, r.d.x, f2); f2 = __builtin_fmaf(T.m2y, r.d.y, f2); f2 = __builtin_fmaf(T.m2z, r.d.z, f2);
+    float f0 = T.q0.x * cv.x;
+    float f1 = T.q0.w * cv.x;
+    float f2 = T.q1.z * cv.x;
+    f0 = __builtin_fmaf(T.q0.y, cv.y, f0); f1 = __builtin_fmaf(T.q1.x, cv.y, f1); f2 = __builtin_fmaf(T.q1.w, cv.y, f2);
+    f0 = __builtin_fmaf(T.q0.z, cv.z, f0); f1 = __builtin_fmaf(T.q1.y, cv.z, f1); f2 = __builtin_fmaf(T.q2.x, cv.z, f2);
+    f0 = __builtin_fmaf(T.q2.y, d.x, f0);  f1 = __builtin_fmaf(T.q3.x, d.x, f1);  f2 = __builtin_fmaf(T.q3.w, d.x, f2);
+    f0 = __builtin_fmaf(T.q2.z, d.y, f0);  f1 = __builtin_fmaf(T.q3.y, d.y, f1);  f2 = __builtin_fmaf(T.q4.x, d.y, f2);
+    f0 = __builtin_fmaf(T.q2.w, d.z, f0);  f1 = __builtin_fmaf(T.q3.z, d.z, f1);  f2 = __builtin_fmaf(T.q4.y, d.z, f2);
     return __builtin_fminf(__builtin_fminf(f0, f1), f2);
 }
 
+// exact re-test of a filter survivor, everything fetched from memory (wave-uniform v: scalar loads)
+__device__ __noinline__ float candidate_t(const SceneView &sc, uint32_t v, f3 o, f3 d)
+{
+    TriRay tr; tr.o = o; tr.d = d; tr.cv = cross3(d, o); tr.ncv = tr.nd = 0.0f;
+    return tri_exact(sc.tri_edges[v], sc.tri_planes[v], tr);
+}
+
 template <int R, bool kCount>
-__device__ __forceinline__ void test_triangle(const TriEdges &T, const SceneView &sc, uint32_t v, RayRegs<R> &rr, unsigned long long &c_cand)
+__device__ __forceinline__ void test_triangle(const TriCoef &T, const SceneView &sc, const RayQueue &qin, uint32_t slot0,
+                                              uint32_t v, HotRays<R> &hr, unsigned long long &c_cand)
 {
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-        float mn = tri_filter_min(T, rr.tr[r]);
-        if (!(mn <= rr.thresh[r])) {                         // rare: ~1 triangle in thousands
+        float mn = filter_min(T, hr.cv[r], hr.d[r]);
+        if (!(mn <= hr.thresh[r])) {                         // rare: a handful of triangles per ray
             if (kCount) c_cand++;
-            float t = tri_exact(T, sc.tri_planes[v], rr.tr[r]);
-            if (kEps < t && t < rr.best_t[r]) { rr.best_t[r] = t; rr.best_v[r] = v; }
+            float4 a = qin.a[slot0 + r * 256u];
+            float t = candidate_t(sc, v, mk(a.x, a.y, a.z), hr.d[r]);
+            if (kEps < t && t < hr.best_t[r]) { hr.best_t[r] = t; hr.best_v[r] = v; }
         }
     }
+}
+
+__device__ __forceinline__ TriCoef load_coef(const float4 *p)
+{
+    TriCoef T;
+    T.q0 = p[0]; T.q1 = p[1]; T.q2 = p[2]; T.q3 = p[3];
+    T.q4 = *reinterpret_cast<const float2 *>(p + 4);
+    return T;
 }
 
 template <int R, int MODE, bool kCount>
@@ -193,45 +218,43 @@ __global__ void __launch_bounds__(256) bounce_kernel(SceneView sc, FrameParams P
     const uint32_t n_rays = wb.counts[bounce];
     const uint32_t base = blockIdx.x * (256u * R);
     if (base >= n_rays) return;                               // uniform per work-group
-    const RayQueue &qin = wb.q[bounce & 1u], &qout = wb.q[(bounce + 1u) & 1u];
+    const RayQueue qin = (bounce & 1u) ? wb.q[1] : wb.q[0];
+    const RayQueue qout = (bounce & 1u) ? wb.q[0] : wb.q[1];
     const bool last_bounce = (bounce + 1u >= P.max_bounce);
+    const uint32_t slot0 = base + threadIdx.x;                // ray r of this lane lives in slot0 + r*256
 
-    PathState st[R];
-    bool valid[R];
-    RayRegs<R> rr;
-    Hit h1[R];
-    bool hit_sphere[R];
+    HotRays<R> hr;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-        uint32_t slot = base + r * 256u + threadIdx.x;
-        valid[r] = slot < n_rays;
-        if (valid[r]) st[r] = load_ray(qin, slot);
-        else { st[r].o = st[r].d = st[r].thr = st[r].rad = mk(0.0f, 0.0f, 0.0f); st[r].pixel = 0; st[r].rng.x = st[r].rng.y = st[r].rng.z = st[r].rng.w = 0; }
-        h1[r].t = kInf; h1[r].material = 0; h1[r].point = h1[r].normal = mk(0.0f, 0.0f, 0.0f);
-        hit_sphere[r] = valid[r] && sphere_pass(sc, st[r].o, st[r].d, h1[r]);          // traverse (:433)
-        rr.tr[r] = make_tri_ray(st[r].o, st[r].d);
-        rr.ncv[r] = valid[r] ? rr.tr[r].ncv : -__builtin_inff();   // empty slot: threshold becomes +inf, nothing passes
-        rr.nd[r] = valid[r] ? rr.tr[r].nd : -__builtin_inff();
-        rr.thresh[r] = __builtin_inff();
-        rr.best_t[r] = kInf; rr.best_v[r] = 0xFFFFFFFFu;
+        const uint32_t slot = slot0 + r * 256u;
+        const bool valid = slot < n_rays;
+        f3 o = mk(0.0f, 0.0f, 0.0f), d = mk(0.0f, 0.0f, 0.0f);
+        if (valid) { float4 a = qin.a[slot], b = qin.b[slot]; o = mk(a.x, a.y, a.z); d = mk(a.w, b.x, b.y); }
+        TriRay tr = make_tri_ray(o, d);
+        hr.cv[r] = tr.cv; hr.d[r] = d;
+        hr.ncv[r] = valid ? tr.ncv : -__builtin_inff();
+        hr.nd[r] = valid ? tr.nd : -__builtin_inff();
+        hr.thresh[r] = __builtin_inff();
+        hr.best_t[r] = kInf; hr.best_v[r] = 0xFFFFFFFFu;
     }
 
     unsigned long long c_cand = 0, c_env = 0;
     const uint32_t n_tri = sc.n_tri_visits;
     // ---- find_closest_mesh (:331-361): every ray against every triangle, in reference order
     if (MODE == kScalar) {
+        const float4 *src = reinterpret_cast<const float4 *>(sc.tri_edges);
         for (uint32_t v0 = 0; v0 < n_tri; v0 += kBoundGroup) {
-            set_thresh<R>(rr, wb.group_bounds[v0 / kBoundGroup]);
+            set_thresh<R>(hr, wb.group_bounds[v0 / kBoundGroup]);
             const uint32_t v1 = min(v0 + (uint32_t)kBoundGroup, n_tri);
+#pragma unroll 2
             for (uint32_t v = v0; v < v1; ++v)
-                test_triangle<R, kCount>(sc.tri_edges[v], sc, v, rr, c_cand);
+                test_triangle<R, kCount>(load_coef(src + (size_t)v * 5), sc, qin, slot0, v, hr, c_cand);
         }
     } else {
         const float4 *src = reinterpret_cast<const float4 *>(sc.tri_edges);
         const uint32_t n_tiles = (n_tri + kTile - 1) / kTile;
         const uint32_t total_f4 = n_tri * 5u;
         float4 stage[5];
-        // tile 0
 #pragma unroll
         for (int k = 0; k < 5; ++k) {
             uint32_t i = k * 256u + threadIdx.x;
@@ -252,14 +275,15 @@ __global__ void __launch_bounds__(256) bounce_kernel(SceneView sc, FrameParams P
             const uint32_t vbase = t * kTile;
             const uint32_t cnt = min((uint32_t)kTile, n_tri - vbase);
             for (uint32_t j0 = 0; j0 < cnt; j0 += kBoundGroup) {
-                set_thresh<R>(rr, wb.group_bounds[(vbase + j0) / kBoundGroup]);
+                set_thresh<R>(hr, wb.group_bounds[(vbase + j0) / kBoundGroup]);
                 const uint32_t j1 = min(j0 + (uint32_t)kBoundGroup, cnt);
+                TriCoef cur = load_coef(buf + j0 * 5);
+#pragma unroll 2
                 for (uint32_t j = j0; j < j1; ++j) {
-                    TriEdges T;
-                    float4 *tp = reinterpret_cast<float4 *>(&T);
-#pragma unroll
-                    for (int k = 0; k < 5; ++k) tp[k] = buf[j * 5 + k];
-                    test_triangle<R, kCount>(T, sc, vbase + j, rr, c_cand);
+                    // prefetch the next record (the slot after the tile's last record is readable LDS)
+                    TriCoef nxt_coef = load_coef(buf + min(j + 1u, (uint32_t)kTile - 1u) * 5);
+                    test_triangle<R, kCount>(cur, sc, qin, slot0, vbase + j, hr, c_cand);
+                    cur = nxt_coef;
                 }
             }
             if (have_next) {
@@ -271,23 +295,27 @@ __global__ void __launch_bounds__(256) bounce_kernel(SceneView sc, FrameParams P
         }
     }
 
-    // ---- closest hit, material response, compaction into the next queue
+    // ---- per ray: reload the path, sphere scan, closest hit, material response, compaction
 #pragma unroll
     for (int r = 0; r < R; ++r) {
+        const uint32_t slot = slot0 + r * 256u;
+        const bool valid = slot < n_rays;
         bool alive = false;
-        PathState &s = st[r];
-        if (valid[r]) {
-            const bool hit_mesh = rr.best_v[r] != 0xFFFFFFFFu;
-            if (!hit_sphere[r] && !hit_mesh) {                                          // :441-445
+        PathState s;
+        if (valid) {
+            s = load_ray(qin, slot);
+            Hit h; h.t = kInf; h.material = 0; h.point = h.normal = mk(0.0f, 0.0f, 0.0f);
+            const bool hit_sphere = sphere_pass(sc, s.o, s.d, h);                        // traverse (:433)
+            const bool hit_mesh = hr.best_v[r] != 0xFFFFFFFFu;
+            if (!hit_sphere && !hit_mesh) {                                              // :441-445
                 f3 bg;
                 if (P.use_envmap) { bg = env_lookup(sc, s.d); if (kCount) c_env++; }
                 else bg = mk(P.background[0], P.background[1], P.background[2]);
                 s.rad = s.rad + bg * s.thr;
             } else {
-                Hit h = h1[r];
-                if (!(h1[r].t < rr.best_t[r])) {                                        // :447
-                    const TriPlane &pl = sc.tri_planes[rr.best_v[r]];
-                    h.t = rr.best_t[r]; h.point = s.o + s.d * rr.best_t[r]; h.normal = mk(pl.nx, pl.ny, pl.nz); h.material = pl.material;
+                if (!(h.t < hr.best_t[r])) {                                             // :447
+                    const TriPlane pl = sc.tri_planes[hr.best_v[r]];
+                    h.t = hr.best_t[r]; h.point = s.o + s.d * hr.best_t[r]; h.normal = mk(pl.nx, pl.ny, pl.nz); h.material = pl.material;
                 }
                 alive = shade_hit(sc, h, s.rng, s.o, s.d, s.thr, s.rad) && !last_bounce;
             }
@@ -297,9 +325,10 @@ __global__ void __launch_bounds__(256) bounce_kernel(SceneView sc, FrameParams P
         const unsigned long long mask = __ballot(alive);
         if (mask) {
             const int lane = threadIdx.x & 63;
+            const int leader = (int)__builtin_ctzll(mask);
             uint32_t wave_base = 0;
-            if (lane == (int)__builtin_ctzll(mask)) wave_base = atomicAdd(&wb.counts[bounce + 1u], (uint32_t)__popcll(mask));
-            wave_base = __shfl(wave_base, (int)__builtin_ctzll(mask));
+            if (lane == leader) wave_base = atomicAdd(&wb.counts[bounce + 1u], (uint32_t)__popcll(mask));
+            wave_base = __shfl(wave_base, leader);
             if (alive) store_ray(qout, wave_base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull)), s);
         }
     }
@@ -310,6 +339,164 @@ __global__ void __launch_bounds__(256) bounce_kernel(SceneView sc, FrameParams P
             atomicAdd(&counters->segments, (unsigned long long)n_rays);
             atomicAdd(&counters->tri_tests, (unsigned long long)n_rays * n_tri);
         }
+    }
+}
+
+// ---- split pipeline: intersect (2-D grid: ray blocks x triangle chunks) + shade ---------------------
+// Every (ray block, triangle chunk) pair is an independent work item of identical cost, so the grid is
+// thousands of equal blocks and the chip stays full on every bounce (the fused kernel above runs
+// n_rays/(256 R) long blocks and loses up to a third of the machine to the last partial round).
+// Chunks merge through one 64-bit atomicMin per ray that found a hit: key = (float bits of t) << 32 |
+// visit index.  t > 0, so the unsigned order of the key is the order of (t, visit index) and the
+// minimum is exactly the hit the reference's in-order scan with `t < max_t` keeps (:349).
+constexpr unsigned long long kNoHitKey = 0xFFFFFFFFFFFFFFFFull;
+
+template <int R, int MODE, bool kCount>
+__global__ void __launch_bounds__(256) intersect_kernel(SceneView sc, WaveBuffers wb, uint32_t bounce, uint32_t chunk_tris, Counters *counters)
+{
+    __shared__ float4 lds_tile[MODE == kLds ? 2 * kTile * 5 : 1];
+    const uint32_t n_rays = wb.counts[bounce];
+    const uint32_t base = blockIdx.x * (256u * R);
+    if (base >= n_rays) return;                               // uniform per work-group
+    const RayQueue qin = (bounce & 1u) ? wb.q[1] : wb.q[0];
+    unsigned long long *best = (bounce & 1u) ? wb.best[1] : wb.best[0];
+    const uint32_t slot0 = base + threadIdx.x;
+    const uint32_t v_begin = blockIdx.y * chunk_tris;
+    const uint32_t v_end = min(v_begin + chunk_tris, sc.n_tri_visits);
+
+    HotRays<R> hr;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const uint32_t slot = slot0 + r * 256u;
+        const bool valid = slot < n_rays;
+        f3 o = mk(0.0f, 0.0f, 0.0f), d = mk(0.0f, 0.0f, 0.0f);
+        if (valid) { float4 a = qin.a[slot], b = qin.b[slot]; o = mk(a.x, a.y, a.z); d = mk(a.w, b.x, b.y); }
+        TriRay tr = make_tri_ray(o, d);
+        hr.cv[r] = tr.cv; hr.d[r] = d;
+        hr.ncv[r] = valid ? tr.ncv : -__builtin_inff();
+        hr.nd[r] = valid ? tr.nd : -__builtin_inff();
+        hr.thresh[r] = __builtin_inff();
+        hr.best_t[r] = kInf; hr.best_v[r] = 0xFFFFFFFFu;
+    }
+    unsigned long long c_cand = 0;
+    const float4 *src = reinterpret_cast<const float4 *>(sc.tri_edges);
+    if (MODE == kScalar) {
+        for (uint32_t v0 = v_begin; v0 < v_end; v0 += kBoundGroup) {        // chunk_tris is a multiple of kBoundGroup
+            set_thresh<R>(hr, wb.group_bounds[v0 / kBoundGroup]);
+            const uint32_t v1 = min(v0 + (uint32_t)kBoundGroup, v_end);
+#pragma unroll 2
+            for (uint32_t v = v0; v < v1; ++v)
+                test_triangle<R, kCount>(load_coef(src + (size_t)v * 5), sc, qin, slot0, v, hr, c_cand);
+        }
+    } else {
+        const uint32_t n_chunk = v_end - v_begin;
+        const uint32_t n_tiles = (n_chunk + kTile - 1) / kTile;
+        const float4 *csrc = src + (size_t)v_begin * 5;
+        const uint32_t total_f4 = n_chunk * 5u;
+        float4 stage[5];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            uint32_t i = k * 256u + threadIdx.x;
+            if (i < total_f4) lds_tile[i] = csrc[i];
+        }
+        __syncthreads();
+        for (uint32_t t = 0; t < n_tiles; ++t) {
+            const uint32_t nxt = (t + 1u) * (kTile * 5u);
+            const bool have_next = (t + 1u < n_tiles);
+            if (have_next) {
+#pragma unroll
+                for (int k = 0; k < 5; ++k) {
+                    uint32_t i = nxt + k * 256u + threadIdx.x;
+                    stage[k] = (i < total_f4) ? csrc[i] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                }
+            }
+            const float4 *buf = lds_tile + (t & 1u) * (kTile * 5);
+            const uint32_t vbase = v_begin + t * kTile;
+            const uint32_t cnt = min((uint32_t)kTile, v_end - vbase);
+            for (uint32_t j0 = 0; j0 < cnt; j0 += kBoundGroup) {
+                set_thresh<R>(hr, wb.group_bounds[(vbase + j0) / kBoundGroup]);
+                const uint32_t j1 = min(j0 + (uint32_t)kBoundGroup, cnt);
+                TriCoef cur = load_coef(buf + j0 * 5);
+#pragma unroll 2
+                for (uint32_t j = j0; j < j1; ++j) {
+                    TriCoef nxt_coef = load_coef(buf + min(j + 1u, (uint32_t)kTile - 1u) * 5);
+                    test_triangle<R, kCount>(cur, sc, qin, slot0, vbase + j, hr, c_cand);
+                    cur = nxt_coef;
+                }
+            }
+            if (have_next) {
+                float4 *dst = lds_tile + ((t + 1u) & 1u) * (kTile * 5);
+#pragma unroll
+                for (int k = 0; k < 5; ++k) dst[k * 256u + threadIdx.x] = stage[k];
+            }
+            __syncthreads();
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+        if (hr.best_v[r] != 0xFFFFFFFFu)
+            atomicMin(&best[slot0 + r * 256u], ((unsigned long long)__float_as_uint(hr.best_t[r]) << 32) | hr.best_v[r]);
+    if (kCount) {
+        atomicAdd(&counters->candidates, c_cand);
+        if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&counters->tri_tests, (unsigned long long)n_rays * (v_end - v_begin));
+    }
+}
+
+// One lane per live ray: sphere scan, pick the nearer hit, material response, termination or
+// compaction into the next queue (wave ballot + prefix popcount, one atomicAdd per wave).
+template <bool kCount>
+__global__ void __launch_bounds__(256) shade_kernel(SceneView sc, FrameParams P, ImageView im, WaveBuffers wb,
+                                                    uint32_t bounce, uint4 *rng_out, Counters *counters)
+{
+    const uint32_t n_rays = wb.counts[bounce];
+    const uint32_t slot = blockIdx.x * 256u + threadIdx.x;
+    if (blockIdx.x * 256u >= n_rays) return;
+    const RayQueue qin = (bounce & 1u) ? wb.q[1] : wb.q[0];
+    const RayQueue qout = (bounce & 1u) ? wb.q[0] : wb.q[1];
+    const unsigned long long *best_in = (bounce & 1u) ? wb.best[1] : wb.best[0];
+    unsigned long long *best_out = (bounce & 1u) ? wb.best[0] : wb.best[1];
+    const bool last_bounce = (bounce + 1u >= P.max_bounce);
+    const bool valid = slot < n_rays;
+    bool alive = false;
+    unsigned long long c_env = 0;
+    PathState s;
+    if (valid) {
+        s = load_ray(qin, slot);
+        const unsigned long long key = best_in[slot];
+        Hit h; h.t = kInf; h.material = 0; h.point = h.normal = mk(0.0f, 0.0f, 0.0f);
+        const bool hit_sphere = sphere_pass(sc, s.o, s.d, h);                            // traverse (:433)
+        const bool hit_mesh = key != kNoHitKey;
+        if (!hit_sphere && !hit_mesh) {                                                  // :441-445
+            f3 bg;
+            if (P.use_envmap) { bg = env_lookup(sc, s.d); if (kCount) c_env++; }
+            else bg = mk(P.background[0], P.background[1], P.background[2]);
+            s.rad = s.rad + bg * s.thr;
+        } else {
+            const float mesh_t = hit_mesh ? __uint_as_float((uint32_t)(key >> 32)) : kInf;
+            if (!(h.t < mesh_t)) {                                                       // :447
+                const TriPlane pl = sc.tri_planes[(uint32_t)key];
+                h.t = mesh_t; h.point = s.o + s.d * mesh_t; h.normal = mk(pl.nx, pl.ny, pl.nz); h.material = pl.material;
+            }
+            alive = shade_hit(sc, h, s.rng, s.o, s.d, s.thr, s.rad) && !last_bounce;
+        }
+        if (!alive) finish_path(P, im, wb, s, rng_out);
+    }
+    const unsigned long long mask = __ballot(alive);
+    if (mask) {
+        const int lane = threadIdx.x & 63;
+        const int leader = (int)__builtin_ctzll(mask);
+        uint32_t wave_base = 0;
+        if (lane == leader) wave_base = atomicAdd(&wb.counts[bounce + 1u], (uint32_t)__popcll(mask));
+        wave_base = __shfl(wave_base, leader);
+        if (alive) {
+            const uint32_t out_slot = wave_base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+            store_ray(qout, out_slot, s);
+            best_out[out_slot] = kNoHitKey;
+        }
+    }
+    if (kCount) {
+        atomicAdd(&counters->env_lookups, c_env);
+        if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&counters->segments, (unsigned long long)n_rays);
     }
 }
 

@@ -179,7 +179,7 @@ struct rtgl_context {
     bool tris_dirty = false, visits_dirty = false;
     FrameParams params{};
     bool have_params = false;
-    int opt_kernel = RTGL_KERNEL_WAVEFRONT, opt_rng_state = 0, opt_counters = 0, opt_wf_rays = 2, opt_wf_mode = kLds;
+    int opt_kernel = RTGL_KERNEL_WAVEFRONT_SPLIT, opt_rng_state = 0, opt_counters = 0, opt_wf_rays = 4, opt_wf_mode = kLds, opt_wf_chunk = 1024;
 };
 
 static int fail(rtgl_context *ctx, int code, const std::string &msg)
@@ -411,7 +411,7 @@ static int ensure_wave_buffers(rtgl_context *ctx, uint32_t n0, uint32_t max_boun
     if (ctx->wave_capacity < n0 || (multi_sample && !ctx->wave_multi)) {
         if (ctx->d_wave) { HIPCHK(ctx, hipFree(ctx->d_wave)); ctx->d_wave = nullptr; }
         // per queue: 4 x 16 B + 4 B per ray; per-pixel state for u_samples > 1: 4 x 16 B
-        size_t q_bytes = (size_t)n0 * 68, bytes = 2 * q_bytes + 256 + (multi_sample ? local_px * 64 : 0);
+        size_t q_bytes = (size_t)n0 * (68 + 8), bytes = 2 * q_bytes + 512 + (multi_sample ? local_px * 64 : 0);
         HIPCHK(ctx, hipMalloc(&ctx->d_wave, bytes));
         ctx->wave_capacity = n0; ctx->wave_multi = multi_sample;
         uint8_t *p = (uint8_t *)ctx->d_wave;
@@ -421,6 +421,7 @@ static int ensure_wave_buffers(rtgl_context *ctx, uint32_t n0, uint32_t max_boun
             ctx->wb.q[q].c = (float4 *)p; p += (size_t)n0 * 16;
             ctx->wb.q[q].rng = (uint4 *)p; p += (size_t)n0 * 16;
         }
+        for (int q = 0; q < 2; ++q) { ctx->wb.best[q] = (unsigned long long *)p; p += (size_t)n0 * 8; }
         for (int q = 0; q < 2; ++q) { ctx->wb.q[q].pixel = (uint32_t *)p; p += (size_t)n0 * 4; }
         p = (uint8_t *)(((uintptr_t)p + 255) & ~(uintptr_t)255);
         if (multi_sample) {
@@ -445,6 +446,17 @@ static void launch_bounce(rtgl_context *ctx, const SceneView &sc, const FramePar
         hipLaunchKernelGGL((bounce_kernel<R, MODE, false>), grid, dim3(256), 0, ctx->stream, sc, P, im, ctx->wb, bounce, rng_out, ctx->d_counters);
 }
 
+template <int R, int MODE>
+static void launch_intersect(rtgl_context *ctx, const SceneView &sc, uint32_t n0, uint32_t bounce)
+{
+    const uint32_t chunk = (uint32_t)ctx->opt_wf_chunk;
+    dim3 grid((n0 + 256u * R - 1) / (256u * R), (sc.n_tri_visits + chunk - 1) / chunk);
+    if (ctx->opt_counters)
+        hipLaunchKernelGGL((intersect_kernel<R, MODE, true>), grid, dim3(256), 0, ctx->stream, sc, ctx->wb, bounce, chunk, ctx->d_counters);
+    else
+        hipLaunchKernelGGL((intersect_kernel<R, MODE, false>), grid, dim3(256), 0, ctx->stream, sc, ctx->wb, bounce, chunk, ctx->d_counters);
+}
+
 static int launch_wavefront(rtgl_context *ctx, const SceneView &sc, const FrameParams &P, const ImageView &im, uint32_t n0, uint4 *rng_out)
 {
     const dim3 gen_grid((n0 + 255) / 256);
@@ -454,6 +466,26 @@ static int launch_wavefront(rtgl_context *ctx, const SceneView &sc, const FrameP
                            ctx->opt_counters ? ctx->d_counters : (Counters *)nullptr);
         for (uint32_t b = 0; b < P.max_bounce; ++b) {
             const int key = ctx->opt_wf_mode * 10 + ctx->opt_wf_rays;
+            if (ctx->opt_kernel == RTGL_KERNEL_WAVEFRONT_SPLIT) {
+                if (sc.n_tri_visits > 0) {
+                    switch (key) {
+                    case 1: launch_intersect<1, kScalar>(ctx, sc, n0, b); break;
+                    case 2: launch_intersect<2, kScalar>(ctx, sc, n0, b); break;
+                    case 4: launch_intersect<4, kScalar>(ctx, sc, n0, b); break;
+                    case 8: launch_intersect<8, kScalar>(ctx, sc, n0, b); break;
+                    case 11: launch_intersect<1, kLds>(ctx, sc, n0, b); break;
+                    case 12: launch_intersect<2, kLds>(ctx, sc, n0, b); break;
+                    case 14: launch_intersect<4, kLds>(ctx, sc, n0, b); break;
+                    case 18: launch_intersect<8, kLds>(ctx, sc, n0, b); break;
+                    default: return fail(ctx, RTGL_ERR_STATE, "unsupported wf_mode / wf_rays combination");
+                    }
+                }
+                if (ctx->opt_counters)
+                    hipLaunchKernelGGL(shade_kernel<true>, gen_grid, dim3(256), 0, ctx->stream, sc, P, im, ctx->wb, b, rng_out, ctx->d_counters);
+                else
+                    hipLaunchKernelGGL(shade_kernel<false>, gen_grid, dim3(256), 0, ctx->stream, sc, P, im, ctx->wb, b, rng_out, ctx->d_counters);
+                continue;
+            }
             switch (key) {
             case 1: launch_bounce<1, kScalar>(ctx, sc, P, im, n0, b, rng_out); break;
             case 2: launch_bounce<2, kScalar>(ctx, sc, P, im, n0, b, rng_out); break;
@@ -512,7 +544,7 @@ extern "C" int rtgl_render_frame(rtgl_context *ctx)
     for (int lr = 0; lr < ctx->local_rows; ++lr) if (rtgl_local_row_to_global(ctx, lr) < im.disp_h) local_disp_rows = lr + 1;
     const uint32_t n0 = (uint32_t)im.disp_w * (uint32_t)local_disp_rows;
     uint4 *rng_out = ctx->opt_rng_state ? ctx->d_rng : nullptr;
-    const bool use_wavefront = ctx->opt_kernel == RTGL_KERNEL_WAVEFRONT && P.max_bounce > 0;
+    const bool use_wavefront = ctx->opt_kernel != RTGL_KERNEL_MEGA && P.max_bounce > 0;
     if (use_wavefront && n0 > 0) { int rc = ensure_wave_buffers(ctx, n0, P.max_bounce, P.samples > 1); if (rc) return rc; }
     HIPCHK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
     if (n0 > 0 && !use_wavefront) {
@@ -642,11 +674,15 @@ extern "C" int rtgl_set_option(rtgl_context *ctx, const char *key, int value)
     ENTER(ctx);
     if (!key) return fail(ctx, RTGL_ERR_INVALID, "key is NULL");
     if (!strcmp(key, "kernel")) {
-        if (value != RTGL_KERNEL_MEGA && value != RTGL_KERNEL_WAVEFRONT) return fail(ctx, RTGL_ERR_INVALID, "unknown kernel variant");
+        if (value != RTGL_KERNEL_MEGA && value != RTGL_KERNEL_WAVEFRONT && value != RTGL_KERNEL_WAVEFRONT_SPLIT)
+            return fail(ctx, RTGL_ERR_INVALID, "unknown kernel variant");
         ctx->opt_kernel = value;
     } else if (!strcmp(key, "wf_rays")) {
-        if (value != 1 && value != 2 && value != 4) return fail(ctx, RTGL_ERR_INVALID, "wf_rays must be 1, 2 or 4");
+        if (value != 1 && value != 2 && value != 4 && value != 8) return fail(ctx, RTGL_ERR_INVALID, "wf_rays must be 1, 2, 4 or 8");
         ctx->opt_wf_rays = value;
+    } else if (!strcmp(key, "wf_chunk")) {
+        if (value < kBoundGroup || value % kBoundGroup) return fail(ctx, RTGL_ERR_INVALID, "wf_chunk must be a positive multiple of 64");
+        ctx->opt_wf_chunk = value;
     } else if (!strcmp(key, "wf_mode")) {
         if (value != kScalar && value != kLds) return fail(ctx, RTGL_ERR_INVALID, "wf_mode must be 0 (scalar) or 1 (lds)");
         ctx->opt_wf_mode = value;
@@ -663,6 +699,7 @@ extern "C" int rtgl_get_option(rtgl_context *ctx, const char *key, int *value)
     if (!strcmp(key, "kernel")) *value = ctx->opt_kernel;
     else if (!strcmp(key, "wf_rays")) *value = ctx->opt_wf_rays;
     else if (!strcmp(key, "wf_mode")) *value = ctx->opt_wf_mode;
+    else if (!strcmp(key, "wf_chunk")) *value = ctx->opt_wf_chunk;
     else if (!strcmp(key, "rng_state")) *value = ctx->opt_rng_state;
     else if (!strcmp(key, "counters")) *value = ctx->opt_counters;
     else return fail(ctx, RTGL_ERR_INVALID, std::string("unknown option ") + key);

@@ -241,41 +241,42 @@ class Context:
         return out
 
 
-def strip_rows_of(height: int, rank: int, world: int, strip_rows: int) -> np.ndarray:
-    """Global row indices owned by `rank`, in local order (host mirror of rtgl_local_row_to_global)."""
-    rows = []
-    n_strips = (height + strip_rows - 1) // strip_rows
-    for s in range(rank, n_strips, world):
-        rows.extend(range(s * strip_rows, min((s + 1) * strip_rows, height)))
-    return np.array(rows, np.int64)
+class FrameLoop:
+    """Pure host logic of the reference's Window::run + Renderer::render frame bookkeeping (no GPU):
+    m_frames is incremented BEFORE render (src/window.cpp:42), u_random = rand() once per frame after
+    srand(0) (src/main.cpp:207, src/renderer.cpp:102), a reset uploads the stale frame count with
+    u_reset_flag = 1 and then zeroes the count (src/renderer.cpp:98,123-127)."""
 
-
-class HeadlessRenderer:
-    """Frame-loop semantics of the reference's Window::run + Renderer::render, without a window:
-    m_frames is incremented BEFORE render (src/window.cpp:42), u_random = rand() once per frame
-    after srand(0) (src/main.cpp:207, src/renderer.cpp:102), a reset uploads the stale frame
-    count and then zeroes it (src/renderer.cpp:98,123-127)."""
-
-    def __init__(self, width: int, height: int, device: int = 0, seed: int = 0, **tiling):
-        self.ctx = Context(width, height, device, **tiling)
-        self.params = FrameParams()
+    def __init__(self, params: FrameParams | None = None, seed: int = 0):
+        self.params = params or FrameParams()
         self.m_frames = 0
         self.m_reset = False
         self._rand = GlibcRand(seed)
 
-    def set_scene(self, scene: Scene):
-        self.ctx.upload_scene(scene)
-        self._has_env = scene.env is not None
-
     def reset_buffer(self):
         self.m_reset = True
 
-    def render_frame(self, sync: bool = True) -> FrameParams:
+    def next_frame(self) -> FrameParams:
         self.m_frames += 1
         p = self.params.replace(frames=self.m_frames, random=self._rand.rand(), reset_flag=int(self.m_reset))
         if self.m_reset:
             self.m_reset = False
             self.m_frames = 0
+        return p
+
+
+class HeadlessRenderer(FrameLoop):
+    """FrameLoop driving a Context: the Python twin of include/rtgl/renderer.h's Renderer."""
+
+    def __init__(self, width: int, height: int, device: int = 0, seed: int = 0, **tiling):
+        super().__init__(seed=seed)
+        self.ctx = Context(width, height, device, **tiling)
+
+    def set_scene(self, scene: Scene):
+        self.ctx.upload_scene(scene)
+
+    def render_frame(self, sync: bool = True) -> FrameParams:
+        p = self.next_frame()
         self.ctx.render(p, sync=sync)
         return p
 

@@ -7,7 +7,7 @@ pytestmark = pytest.mark.gpu
 
 
 # (kernel, wf_mode, wf_rays): megakernel, wavefront with scalar-fed / LDS-tiled triangle pass
-VARIANTS = [(0, 0, 1), (1, 0, 1), (1, 0, 2), (1, 0, 4), (1, 1, 1), (1, 1, 2), (1, 1, 4)]
+VARIANTS = [(0, 0, 1), (1, 0, 1), (1, 0, 4), (1, 1, 2), (1, 1, 4), (2, 0, 1), (2, 0, 4), (2, 0, 8), (2, 1, 1), (2, 1, 2), (2, 1, 4), (2, 1, 8)]
 
 
 def run_both(rt, oracle, scene, params, W, H, frames=1, rng_state=True, reset_at=None, variant=None):
@@ -16,6 +16,7 @@ def run_both(rt, oracle, scene, params, W, H, frames=1, rng_state=True, reset_at
     ctx.upload_scene(scene)
     if variant is not None:
         ctx.set_option("kernel", variant[0]); ctx.set_option("wf_mode", variant[1]); ctx.set_option("wf_rays", variant[2])
+        ctx.set_option("wf_chunk", 128)      # small chunks so that even the small test meshes span several work items
     if rng_state:
         ctx.set_option("rng_state", 1)
     ctx.set_option("counters", 1)
@@ -56,7 +57,7 @@ def test_variants_mesh_env(rt, oracle, variant):
     assert r["cnt_g"]["triangle_tests"] == r["cnt_o"]["triangle_tests"]
 
 
-@pytest.mark.parametrize("variant", [(0, 0, 1), (1, 1, 2), (1, 0, 4)])
+@pytest.mark.parametrize("variant", [(0, 0, 1), (1, 1, 2), (2, 1, 4), (2, 0, 8)])
 def test_two_samples_per_frame(rt, oracle, variant):
     sc = rt.scenes
     r = run_both(rt, oracle, sc.scene_mesh(20, 10, env_size=16), sc.params_c2().replace(samples=2), 64, 64, frames=2, variant=variant)
