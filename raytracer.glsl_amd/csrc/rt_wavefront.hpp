@@ -351,10 +351,45 @@ __global__ void __launch_bounds__(256) bounce_kernel(SceneView sc, FrameParams P
 // minimum is exactly the hit the reference's in-order scan with `t < max_t` keeps (:349).
 constexpr unsigned long long kNoHitKey = 0xFFFFFFFFFFFFFFFFull;
 
+// Hot-loop state of the split intersect kernel: 9 VGPRs per ray.  Filter survivors are not examined in
+// the loop at all: their (ray, triangle) pair is parked in a small per-lane LDS list and drained after
+// the scan, where the exact reference-order test runs with everything fetched from memory and a hit
+// goes straight to the ray's atomicMin key.
+template <int R>
+struct ScanRays {
+    f3 cv[R], d[R];
+    float ncv[R], nd[R];
+    float thresh[R];
+};
+constexpr int kCandSlots = 16;          // parked candidates per lane per work item
+constexpr uint32_t kMaxChunk = 4096;    // candidate entry = ray (4 bits) << 12 | triangle offset in chunk (12 bits)
+
+template <int R>
+__device__ __forceinline__ void scan_triangle(const TriCoef &T, const ScanRays<R> &sr, uint32_t off, uint16_t *cand, uint32_t &n_cand)
+{
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        float mn = filter_min(T, sr.cv[r], sr.d[r]);
+        if (!(mn <= sr.thresh[r])) {                                     // rare
+            if (n_cand < (uint32_t)kCandSlots) cand[n_cand * 256u] = (uint16_t)((r << 12) | off);
+            n_cand++;                                                    // > kCandSlots marks overflow
+        }
+    }
+}
+
+__device__ __forceinline__ void exact_and_merge(const SceneView &sc, const RayQueue &qin, unsigned long long *best, uint32_t slot, uint32_t v)
+{
+    float4 a = qin.a[slot], b = qin.b[slot];
+    TriRay tr; tr.o = mk(a.x, a.y, a.z); tr.d = mk(a.w, b.x, b.y); tr.cv = cross3(tr.d, tr.o); tr.ncv = tr.nd = 0.0f;
+    float t = tri_exact(sc.tri_edges[v], sc.tri_planes[v], tr);
+    if (kEps < t && t < kInf) atomicMin(&best[slot], ((unsigned long long)__float_as_uint(t) << 32) | v);
+}
+
 template <int R, int MODE, bool kCount>
 __global__ void __launch_bounds__(256) intersect_kernel(SceneView sc, WaveBuffers wb, uint32_t bounce, uint32_t chunk_tris, Counters *counters)
 {
-    __shared__ float4 lds_tile[MODE == kLds ? 2 * kTile * 5 : 1];
+    __shared__ float4 lds_tile[MODE == kLds ? kTile * 5 : 1];
+    __shared__ uint16_t lds_cand[kCandSlots * 256];
     const uint32_t n_rays = wb.counts[bounce];
     const uint32_t base = blockIdx.x * (256u * R);
     if (base >= n_rays) return;                               // uniform per work-group
@@ -364,7 +399,7 @@ __global__ void __launch_bounds__(256) intersect_kernel(SceneView sc, WaveBuffer
     const uint32_t v_begin = blockIdx.y * chunk_tris;
     const uint32_t v_end = min(v_begin + chunk_tris, sc.n_tri_visits);
 
-    HotRays<R> hr;
+    ScanRays<R> sr;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const uint32_t slot = slot0 + r * 256u;
@@ -372,72 +407,71 @@ __global__ void __launch_bounds__(256) intersect_kernel(SceneView sc, WaveBuffer
         f3 o = mk(0.0f, 0.0f, 0.0f), d = mk(0.0f, 0.0f, 0.0f);
         if (valid) { float4 a = qin.a[slot], b = qin.b[slot]; o = mk(a.x, a.y, a.z); d = mk(a.w, b.x, b.y); }
         TriRay tr = make_tri_ray(o, d);
-        hr.cv[r] = tr.cv; hr.d[r] = d;
-        hr.ncv[r] = valid ? tr.ncv : -__builtin_inff();
-        hr.nd[r] = valid ? tr.nd : -__builtin_inff();
-        hr.thresh[r] = __builtin_inff();
-        hr.best_t[r] = kInf; hr.best_v[r] = 0xFFFFFFFFu;
+        sr.cv[r] = tr.cv; sr.d[r] = d;
+        sr.ncv[r] = valid ? tr.ncv : -__builtin_inff();       // empty slot: threshold +inf, nothing survives
+        sr.nd[r] = valid ? tr.nd : -__builtin_inff();
+        sr.thresh[r] = __builtin_inff();
     }
-    unsigned long long c_cand = 0;
+    uint16_t *cand = lds_cand + threadIdx.x;                  // entry k of this lane at cand[k * 256]
+    uint32_t n_cand = 0;
     const float4 *src = reinterpret_cast<const float4 *>(sc.tri_edges);
     if (MODE == kScalar) {
         for (uint32_t v0 = v_begin; v0 < v_end; v0 += kBoundGroup) {        // chunk_tris is a multiple of kBoundGroup
-            set_thresh<R>(hr, wb.group_bounds[v0 / kBoundGroup]);
+            const float2 gb = wb.group_bounds[v0 / kBoundGroup];
+#pragma unroll
+            for (int r = 0; r < R; ++r) sr.thresh[r] = -(__builtin_fmaf(gb.x, sr.ncv[r], gb.y * sr.nd[r]) + 1e-30f);
             const uint32_t v1 = min(v0 + (uint32_t)kBoundGroup, v_end);
 #pragma unroll 2
             for (uint32_t v = v0; v < v1; ++v)
-                test_triangle<R, kCount>(load_coef(src + (size_t)v * 5), sc, qin, slot0, v, hr, c_cand);
+                scan_triangle<R>(load_coef(src + (size_t)v * 5), sr, v - v_begin, cand, n_cand);
         }
     } else {
-        const uint32_t n_chunk = v_end - v_begin;
-        const uint32_t n_tiles = (n_chunk + kTile - 1) / kTile;
-        const float4 *csrc = src + (size_t)v_begin * 5;
-        const uint32_t total_f4 = n_chunk * 5u;
-        float4 stage[5];
-#pragma unroll
-        for (int k = 0; k < 5; ++k) {
-            uint32_t i = k * 256u + threadIdx.x;
-            if (i < total_f4) lds_tile[i] = csrc[i];
-        }
-        __syncthreads();
+        // tiles of kTile records: HBM -> LDS with coalesced 16-byte loads (thread i moves float4 i, i+256, ...),
+        // then every lane reads the records back as broadcasts.  No register staging across the scan:
+        // the other work-groups resident on the CU cover the fill latency.
+        const uint32_t n_tiles = (v_end - v_begin + kTile - 1) / kTile;
         for (uint32_t t = 0; t < n_tiles; ++t) {
-            const uint32_t nxt = (t + 1u) * (kTile * 5u);
-            const bool have_next = (t + 1u < n_tiles);
-            if (have_next) {
-#pragma unroll
-                for (int k = 0; k < 5; ++k) {
-                    uint32_t i = nxt + k * 256u + threadIdx.x;
-                    stage[k] = (i < total_f4) ? csrc[i] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                }
-            }
-            const float4 *buf = lds_tile + (t & 1u) * (kTile * 5);
             const uint32_t vbase = v_begin + t * kTile;
             const uint32_t cnt = min((uint32_t)kTile, v_end - vbase);
+            const float4 *tsrc = src + (size_t)vbase * 5;
+            if (t > 0) __syncthreads();
+#pragma unroll
+            for (int k = 0; k < 5; ++k) {
+                uint32_t i = k * 256u + threadIdx.x;
+                if (i < cnt * 5u) lds_tile[i] = tsrc[i];
+            }
+            __syncthreads();
             for (uint32_t j0 = 0; j0 < cnt; j0 += kBoundGroup) {
-                set_thresh<R>(hr, wb.group_bounds[(vbase + j0) / kBoundGroup]);
+                const float2 gb = wb.group_bounds[(vbase + j0) / kBoundGroup];
+#pragma unroll
+                for (int r = 0; r < R; ++r) sr.thresh[r] = -(__builtin_fmaf(gb.x, sr.ncv[r], gb.y * sr.nd[r]) + 1e-30f);
                 const uint32_t j1 = min(j0 + (uint32_t)kBoundGroup, cnt);
-                TriCoef cur = load_coef(buf + j0 * 5);
+                TriCoef cur = load_coef(lds_tile + j0 * 5);
 #pragma unroll 2
                 for (uint32_t j = j0; j < j1; ++j) {
-                    TriCoef nxt_coef = load_coef(buf + min(j + 1u, (uint32_t)kTile - 1u) * 5);
-                    test_triangle<R, kCount>(cur, sc, qin, slot0, vbase + j, hr, c_cand);
+                    TriCoef nxt_coef = load_coef(lds_tile + min(j + 1u, (uint32_t)kTile - 1u) * 5);
+                    scan_triangle<R>(cur, sr, vbase - v_begin + j, cand, n_cand);
                     cur = nxt_coef;
                 }
             }
-            if (have_next) {
-                float4 *dst = lds_tile + ((t + 1u) & 1u) * (kTile * 5);
-#pragma unroll
-                for (int k = 0; k < 5; ++k) dst[k * 256u + threadIdx.x] = stage[k];
-            }
-            __syncthreads();
         }
     }
-#pragma unroll
-    for (int r = 0; r < R; ++r)
-        if (hr.best_v[r] != 0xFFFFFFFFu)
-            atomicMin(&best[slot0 + r * 256u], ((unsigned long long)__float_as_uint(hr.best_t[r]) << 32) | hr.best_v[r]);
+    // ---- drain: exact test (reference operation order) of the parked survivors
+    if (n_cand <= (uint32_t)kCandSlots) {
+        for (uint32_t k = 0; k < n_cand; ++k) {
+            const uint32_t e = cand[k * 256u];
+            exact_and_merge(sc, qin, best, slot0 + (e >> 12) * 256u, v_begin + (e & 4095u));
+        }
+    } else {
+        // more survivors than slots (stacked coplanar geometry): re-test this lane's rays against the whole chunk
+        for (int r = 0; r < R; ++r) {
+            const uint32_t slot = slot0 + r * 256u;
+            if (slot < n_rays)
+                for (uint32_t v = v_begin; v < v_end; ++v) exact_and_merge(sc, qin, best, slot, v);
+        }
+    }
     if (kCount) {
-        atomicAdd(&counters->candidates, c_cand);
+        atomicAdd(&counters->candidates, (unsigned long long)n_cand);
         if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&counters->tri_tests, (unsigned long long)n_rays * (v_end - v_begin));
     }
 }

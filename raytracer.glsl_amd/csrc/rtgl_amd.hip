@@ -179,7 +179,7 @@ struct rtgl_context {
     bool tris_dirty = false, visits_dirty = false;
     FrameParams params{};
     bool have_params = false;
-    int opt_kernel = RTGL_KERNEL_WAVEFRONT_SPLIT, opt_rng_state = 0, opt_counters = 0, opt_wf_rays = 4, opt_wf_mode = kLds, opt_wf_chunk = 1024;
+    int opt_kernel = RTGL_KERNEL_WAVEFRONT_SPLIT, opt_rng_state = 0, opt_counters = 0, opt_wf_rays = 4, opt_wf_mode = kLds, opt_wf_chunk = 512;
 };
 
 static int fail(rtgl_context *ctx, int code, const std::string &msg)
@@ -681,7 +681,7 @@ extern "C" int rtgl_set_option(rtgl_context *ctx, const char *key, int value)
         if (value != 1 && value != 2 && value != 4 && value != 8) return fail(ctx, RTGL_ERR_INVALID, "wf_rays must be 1, 2, 4 or 8");
         ctx->opt_wf_rays = value;
     } else if (!strcmp(key, "wf_chunk")) {
-        if (value < kBoundGroup || value % kBoundGroup) return fail(ctx, RTGL_ERR_INVALID, "wf_chunk must be a positive multiple of 64");
+        if (value < kBoundGroup || value % kBoundGroup || (uint32_t)value > kMaxChunk) return fail(ctx, RTGL_ERR_INVALID, "wf_chunk must be a multiple of 64 in [64, 4096]");
         ctx->opt_wf_chunk = value;
     } else if (!strcmp(key, "wf_mode")) {
         if (value != kScalar && value != kLds) return fail(ctx, RTGL_ERR_INVALID, "wf_mode must be 0 (scalar) or 1 (lds)");

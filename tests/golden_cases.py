@@ -68,6 +68,7 @@ def build_cases(sc):
     add("mesh_backfacing", lambda: scene_backfacing(sc), 64, 64, frame_sequence(sc, P2.replace(use_dof=0), 1))
     add("mesh_two_meshes_overlap", lambda: scene_two_meshes(sc), 96, 64, frame_sequence(sc, P2.replace(use_dof=0), 2))
     add("mesh_7k_bounce8", lambda: sc.scene_mesh(70, 50, env_size=64), 96, 64, frame_sequence(sc, P2, 1))
+    add("mesh_stacked_duplicates", lambda: scene_stacked(sc), 64, 64, frame_sequence(sc, P2.replace(use_dof=0, max_bounce=4), 2))
     add("mesh_odd_materials", lambda: scene_odd_materials(sc), 96, 64, frame_sequence(sc, P2.replace(use_dof=0), 2))
     # --- environment: tiny high-contrast cube (face edges, clamp), RGB (3-channel) cube, incomplete cube, background colour
     add("env_noise_cube", lambda: scene_env_only(sc, sc.noise_cubemap(4, 4)), 128, 128, frame_sequence(sc, P2.replace(max_bounce=2), 1))
@@ -143,6 +144,17 @@ def scene_odd_materials(sc):
     quad = np.repeat(np.arange(v.shape[0] // 6), 6)
     v[:, 3] = w[quad % len(w)]
     s.vertices = v
+    return s
+
+
+def scene_stacked(sc):
+    """30 exact copies of one quad in front of a small grid: every ray through the quad has 60
+    coincident candidate triangles (equal t: the first visit must win, :349), which also overflows
+    the HIP scan's per-lane candidate list and exercises its re-test fallback."""
+    s = sc.scene_mesh(10, 5, env_size=16)
+    quad = np.array([[-8, -6, 2, 0], [-8, 4, 2, 0], [9, 4, 2, 0], [-8, -6, 2, 7], [9, 4, 2, 7], [9, -6, 2, 7]], np.float32)
+    s.vertices = np.concatenate([s.vertices[:150], np.tile(quad, (30, 1)), s.vertices[150:]], axis=0)
+    s.meshes = sc.make_meshes([(0, s.vertices.shape[0] // 3, 0)])
     return s
 
 

@@ -1,0 +1,104 @@
+"""BASELINE.json's full sizes on the GPU: size-independent properties + spot checks against the
+oracle on a bounded sample (the oracle needs minutes per full frame).
+
+  * every kernel variant produces the bit-identical image (they share no code path for the triangle
+    scan: megakernel / fused wavefront / split wavefront, scalar-fed / LDS-tiled, 1..8 rays per lane);
+  * strips of the full-size frame re-rendered by the CPU oracle match bit-for-bit;
+  * row-strip tiling (2 and 3 contexts) reassembles to the single-context image, bit-for-bit;
+  * counters: paths = pixels, segments within [paths, paths*bounces], tests = segments * triangles.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def render(rt, cfg_name, frames=1, options=(), tiling=None, counters=False):
+    sc = rt.scenes
+    cfg = sc.CONFIGS[cfg_name]
+    W, H = cfg["width"], cfg["height"]
+    scene = cfg["scene"]()
+    ctx = rt.host.Context(W, H, **(tiling or {}))
+    for k, v in options:
+        ctx.set_option(k, v)
+    if counters:
+        ctx.set_option("counters", 1)
+    ctx.upload_scene(scene)
+    g = sc.GlibcRand(0)
+    plist = []
+    for f in range(1, frames + 1):
+        p = cfg["params"]().replace(frames=f, random=g.rand())
+        ctx.render(p)
+        plist.append(p)
+    img = ctx.read_image()
+    cnt = ctx.counters() if counters else None
+    rows = ctx.global_rows()
+    ctx.close()
+    return img, cnt, rows, scene, plist
+
+
+@pytest.fixture(scope="module")
+def c2_reference_image(rt):
+    return render(rt, "C2", frames=2, counters=True)
+
+
+def test_c2_counters(c2_reference_image, rt):
+    img, cnt, rows, scene, plist = c2_reference_image
+    px = 1920 * 1080
+    assert cnt["paths"] == px
+    assert px <= cnt["segments"] <= px * 8
+    assert cnt["triangle_tests"] == cnt["segments"] * scene.n_triangles
+    assert 0 < cnt["env_lookups"] <= px
+    assert np.isfinite(img).all() and (img[..., 3] == 1.0).all()
+
+
+@pytest.mark.parametrize("variant", [(0, 0, 1, 1024), (1, 1, 2, 1024), (2, 0, 2, 512), (2, 1, 8, 256), (2, 1, 1, 2560)])
+def test_c2_all_kernel_variants_identical(variant, c2_reference_image, rt):
+    base = c2_reference_image[0]
+    opts = (("kernel", variant[0]), ("wf_mode", variant[1]), ("wf_rays", variant[2]), ("wf_chunk", variant[3]))
+    img = render(rt, "C2", frames=2, options=opts)[0]
+    assert (img.view(np.uint32) == base.view(np.uint32)).all()
+
+
+def test_c2_strips_match_oracle(c2_reference_image, rt, oracle):
+    """Five 8-row strips spread over the frame (1.5% of the pixels), two accumulated frames."""
+    img, _, _, scene, plist = c2_reference_image
+    H, W = img.shape[:2]
+    want = np.zeros_like(img)
+    strips = [0, 264, 536, 808, 1072]
+    for p in plist:
+        for y0 in strips:
+            oracle.render(scene, p, want, rect=(0, y0, W, y0 + 8), threads=16)
+    for y0 in strips:
+        assert (img[y0:y0 + 8].view(np.uint32) == want[y0:y0 + 8].view(np.uint32)).all(), f"strip at row {y0}"
+
+
+@pytest.mark.parametrize("world,strip", [(2, 16), (3, 8)])
+def test_c2_tiled_contexts_reassemble_bit_identically(world, strip, c2_reference_image, rt):
+    base = c2_reference_image[0]
+    full = np.zeros_like(base)
+    for rank in range(world):
+        img, _, rows, _, _ = render(rt, "C2", frames=2, tiling=dict(rank=rank, world=world, strip_rows=strip))
+        assert (rows == rt.tiling.strip_rows_of(1080, rank, world, strip)).all()
+        full[rows] = img
+    assert (full.view(np.uint32) == base.view(np.uint32)).all()
+
+
+def test_c4_100k_triangles_variants_agree_and_match_oracle_strip(rt, oracle):
+    a, cnt, _, scene, plist = render(rt, "C4", frames=1, counters=True)
+    b = render(rt, "C4", frames=1, options=(("kernel", 2), ("wf_mode", 0), ("wf_rays", 4)))[0]
+    assert (a.view(np.uint32) == b.view(np.uint32)).all()
+    assert cnt["triangle_tests"] == cnt["segments"] * 100000
+    want = np.zeros_like(a)
+    oracle.render(scene, plist[0], want, rect=(0, 536, 1920, 544), threads=16)
+    assert (a[536:544].view(np.uint32) == want[536:544].view(np.uint32)).all()
+
+
+def test_c5_2160p_16_bounces_wide_dof(rt, oracle):
+    a, cnt, _, scene, plist = render(rt, "C5", frames=1, counters=True)
+    assert cnt["paths"] == 3840 * 2160 and cnt["segments"] <= cnt["paths"] * 16
+    b = render(rt, "C5", frames=1, options=(("kernel", 1), ("wf_mode", 1), ("wf_rays", 2)))[0]
+    assert (a.view(np.uint32) == b.view(np.uint32)).all()
+    want = np.zeros_like(a)
+    oracle.render(scene, plist[0], want, rect=(0, 1080, 3840, 1084), threads=16)
+    assert (a[1080:1084].view(np.uint32) == want[1080:1084].view(np.uint32)).all()
