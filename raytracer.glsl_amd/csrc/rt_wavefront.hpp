@@ -391,13 +391,16 @@ __global__ void __launch_bounds__(256) intersect_kernel(SceneView sc, WaveBuffer
     __shared__ float4 lds_tile[MODE == kLds ? kTile * 5 : 1];
     __shared__ uint16_t lds_cand[kCandSlots * 256];
     const uint32_t n_rays = wb.counts[bounce];
-    const uint32_t base = blockIdx.x * (256u * R);
-    if (base >= n_rays) return;                               // uniform per work-group
     const RayQueue qin = (bounce & 1u) ? wb.q[1] : wb.q[0];
     unsigned long long *best = (bounce & 1u) ? wb.best[1] : wb.best[0];
-    const uint32_t slot0 = base + threadIdx.x;
     const uint32_t v_begin = blockIdx.y * chunk_tris;
     const uint32_t v_end = min(v_begin + chunk_tris, sc.n_tri_visits);
+    unsigned long long c_cand_total = 0;
+    // grid-stride over ray blocks: the host sizes gridDim.x from the previous frame's ray counts (the
+    // live count is only known on the device); any grid size is correct
+    for (uint32_t base = blockIdx.x * (256u * R); base < n_rays; base += gridDim.x * (256u * R)) {
+    const uint32_t slot0 = base + threadIdx.x;
+    if (base != blockIdx.x * (256u * R)) __syncthreads();     // LDS of the previous ray block is still being read
 
     ScanRays<R> sr;
 #pragma unroll
@@ -470,8 +473,10 @@ __global__ void __launch_bounds__(256) intersect_kernel(SceneView sc, WaveBuffer
                 for (uint32_t v = v_begin; v < v_end; ++v) exact_and_merge(sc, qin, best, slot, v);
         }
     }
+    c_cand_total += n_cand;
+    }
     if (kCount) {
-        atomicAdd(&counters->candidates, (unsigned long long)n_cand);
+        atomicAdd(&counters->candidates, c_cand_total);
         if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&counters->tri_tests, (unsigned long long)n_rays * (v_end - v_begin));
     }
 }
@@ -483,16 +488,16 @@ __global__ void __launch_bounds__(256) shade_kernel(SceneView sc, FrameParams P,
                                                     uint32_t bounce, uint4 *rng_out, Counters *counters)
 {
     const uint32_t n_rays = wb.counts[bounce];
-    const uint32_t slot = blockIdx.x * 256u + threadIdx.x;
-    if (blockIdx.x * 256u >= n_rays) return;
     const RayQueue qin = (bounce & 1u) ? wb.q[1] : wb.q[0];
     const RayQueue qout = (bounce & 1u) ? wb.q[0] : wb.q[1];
     const unsigned long long *best_in = (bounce & 1u) ? wb.best[1] : wb.best[0];
     unsigned long long *best_out = (bounce & 1u) ? wb.best[0] : wb.best[1];
     const bool last_bounce = (bounce + 1u >= P.max_bounce);
+    unsigned long long c_env = 0;
+    for (uint32_t blk = blockIdx.x; blk * 256u < n_rays; blk += gridDim.x) {      // grid-stride, see intersect_kernel
+    const uint32_t slot = blk * 256u + threadIdx.x;
     const bool valid = slot < n_rays;
     bool alive = false;
-    unsigned long long c_env = 0;
     PathState s;
     if (valid) {
         s = load_ray(qin, slot);
@@ -527,6 +532,7 @@ __global__ void __launch_bounds__(256) shade_kernel(SceneView sc, FrameParams P,
             store_ray(qout, out_slot, s);
             best_out[out_slot] = kNoHitKey;
         }
+    }
     }
     if (kCount) {
         atomicAdd(&counters->env_lookups, c_env);

@@ -174,6 +174,10 @@ struct rtgl_context {
     float2 *d_group_bounds = nullptr;
     void *d_wave = nullptr; size_t wave_capacity = 0; bool wave_multi = false;   // queues (+ per-pixel state when u_samples > 1)
     uint32_t *d_counts = nullptr; uint32_t counts_capacity = 0;
+    uint32_t *h_counts = nullptr;            // pinned: ray counts per bounce of the most recent finished frame
+    hipEvent_t counts_ev = nullptr; bool counts_pending = false, counts_valid = false;
+    uint32_t counts_n0 = 0, counts_len = 0;
+    std::vector<uint32_t> est_counts;        // grid-size estimates for the next frame
     WaveBuffers wb{};
 
     bool tris_dirty = false, visits_dirty = false;
@@ -255,6 +259,8 @@ extern "C" void rtgl_destroy(rtgl_context *ctx)
     void *ptrs[] = { ctx->d_spheres, ctx->d_materials, ctx->d_vertices, ctx->d_sphere_visits, ctx->d_edges, ctx->d_planes,
                      ctx->d_env, ctx->d_image_own, ctx->d_rng, ctx->d_counters, ctx->d_u8, ctx->d_group_bounds, ctx->d_wave, ctx->d_counts };
     for (void *p : ptrs) if (p) (void)hipFree(p);
+    if (ctx->h_counts) (void)hipHostFree(ctx->h_counts);
+    if (ctx->counts_ev) (void)hipEventDestroy(ctx->counts_ev);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
@@ -405,7 +411,10 @@ static int ensure_wave_buffers(rtgl_context *ctx, uint32_t n0, uint32_t max_boun
     if (ctx->counts_capacity < max_bounce + 2) {
         if (ctx->d_counts) { HIPCHK(ctx, hipFree(ctx->d_counts)); ctx->d_counts = nullptr; }
         HIPCHK(ctx, hipMalloc((void **)&ctx->d_counts, (size_t)(max_bounce + 2) * sizeof(uint32_t)));
-        ctx->counts_capacity = max_bounce + 2;
+        if (ctx->h_counts) { HIPCHK(ctx, hipHostFree(ctx->h_counts)); ctx->h_counts = nullptr; }
+        HIPCHK(ctx, hipHostMalloc((void **)&ctx->h_counts, (size_t)(max_bounce + 2) * sizeof(uint32_t), hipHostMallocDefault));
+        if (!ctx->counts_ev) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->counts_ev, hipEventDisableTiming));
+        ctx->counts_capacity = max_bounce + 2; ctx->counts_pending = ctx->counts_valid = false; ctx->est_counts.clear();
     }
     const size_t local_px = (size_t)std::max(ctx->local_rows, 1) * ctx->width;
     if (ctx->wave_capacity < n0 || (multi_sample && !ctx->wave_multi)) {
@@ -446,11 +455,21 @@ static void launch_bounce(rtgl_context *ctx, const SceneView &sc, const FramePar
         hipLaunchKernelGGL((bounce_kernel<R, MODE, false>), grid, dim3(256), 0, ctx->stream, sc, P, im, ctx->wb, bounce, rng_out, ctx->d_counters);
 }
 
+// Upper estimate of the rays entering `bounce`, for grid sizing only (kernels grid-stride, so a low
+// estimate costs time, never correctness): last finished frame's count + 10 % + 2048, capped by n0.
+static uint32_t estimate_rays(const rtgl_context *ctx, uint32_t n0, uint32_t bounce)
+{
+    if (bounce == 0 || bounce >= ctx->est_counts.size()) return n0;
+    uint64_t e = (uint64_t)ctx->est_counts[bounce] + ctx->est_counts[bounce] / 10 + 2048;
+    return (uint32_t)std::min<uint64_t>(e, n0);
+}
+
 template <int R, int MODE>
 static void launch_intersect(rtgl_context *ctx, const SceneView &sc, uint32_t n0, uint32_t bounce)
 {
     const uint32_t chunk = (uint32_t)ctx->opt_wf_chunk;
-    dim3 grid((n0 + 256u * R - 1) / (256u * R), (sc.n_tri_visits + chunk - 1) / chunk);
+    const uint32_t est = estimate_rays(ctx, n0, bounce);
+    dim3 grid((est + 256u * R - 1) / (256u * R), (sc.n_tri_visits + chunk - 1) / chunk);
     if (ctx->opt_counters)
         hipLaunchKernelGGL((intersect_kernel<R, MODE, true>), grid, dim3(256), 0, ctx->stream, sc, ctx->wb, bounce, chunk, ctx->d_counters);
     else
@@ -460,6 +479,12 @@ static void launch_intersect(rtgl_context *ctx, const SceneView &sc, uint32_t n0
 static int launch_wavefront(rtgl_context *ctx, const SceneView &sc, const FrameParams &P, const ImageView &im, uint32_t n0, uint4 *rng_out)
 {
     const dim3 gen_grid((n0 + 255) / 256);
+    // pick up the ray counts of the most recent finished frame (never blocks)
+    if (ctx->counts_pending && hipEventQuery(ctx->counts_ev) == hipSuccess) {
+        ctx->counts_pending = false;
+        if (ctx->counts_n0 == n0) ctx->est_counts.assign(ctx->h_counts, ctx->h_counts + ctx->counts_len);
+        else ctx->est_counts.clear();
+    }
     for (uint32_t s = 0; s < P.samples; ++s) {
         HIPCHK(ctx, hipMemsetAsync(ctx->d_counts, 0, (size_t)(P.max_bounce + 2) * sizeof(uint32_t), ctx->stream));
         hipLaunchKernelGGL(generate_rays_kernel, gen_grid, dim3(256), 0, ctx->stream, P, im, ctx->wb, s, n0,
@@ -480,10 +505,11 @@ static int launch_wavefront(rtgl_context *ctx, const SceneView &sc, const FrameP
                     default: return fail(ctx, RTGL_ERR_STATE, "unsupported wf_mode / wf_rays combination");
                     }
                 }
+                const dim3 shade_grid((estimate_rays(ctx, n0, b) + 255) / 256);
                 if (ctx->opt_counters)
-                    hipLaunchKernelGGL(shade_kernel<true>, gen_grid, dim3(256), 0, ctx->stream, sc, P, im, ctx->wb, b, rng_out, ctx->d_counters);
+                    hipLaunchKernelGGL(shade_kernel<true>, shade_grid, dim3(256), 0, ctx->stream, sc, P, im, ctx->wb, b, rng_out, ctx->d_counters);
                 else
-                    hipLaunchKernelGGL(shade_kernel<false>, gen_grid, dim3(256), 0, ctx->stream, sc, P, im, ctx->wb, b, rng_out, ctx->d_counters);
+                    hipLaunchKernelGGL(shade_kernel<false>, shade_grid, dim3(256), 0, ctx->stream, sc, P, im, ctx->wb, b, rng_out, ctx->d_counters);
                 continue;
             }
             switch (key) {
@@ -501,6 +527,12 @@ static int launch_wavefront(rtgl_context *ctx, const SceneView &sc, const FrameP
     if (P.samples > 1u) {
         hipLaunchKernelGGL(resolve_kernel, gen_grid, dim3(256), 0, ctx->stream, P, im, ctx->wb);
         HIPCHK(ctx, hipGetLastError());
+    }
+    if (!ctx->counts_pending) {      // feed the next frames' grid sizes; skipped while an earlier copy is in flight
+        ctx->counts_len = P.max_bounce + 1; ctx->counts_n0 = n0;
+        HIPCHK(ctx, hipMemcpyAsync(ctx->h_counts, ctx->d_counts, (size_t)ctx->counts_len * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipEventRecord(ctx->counts_ev, ctx->stream));
+        ctx->counts_pending = true;
     }
     return RTGL_OK;
 }
