@@ -30,12 +30,14 @@ def scene_bytes(scene) -> int:
             + 32 * scene.materials.shape[0])
 
 
-def algorithmic_bytes(width, height, counters, scene, reset=False) -> float:
-    """image read+write (32 B/px, 16 on a reset frame) + one scene stream per
-    256-ray group per bounce pass (segments/256 groups with perfect compaction) + 16 B per
-    environment lookup (four RGBA8 texels)."""
+def algorithmic_bytes(width, height, counters, scene, reset=False) -> dict:
+    """SURVEY.md 8(d3), per frame: image read+write (32 B/px, 16 on a reset frame) + one scene stream
+    per 256-ray group per bounce pass (segments/256 groups with perfect compaction) + 16 B per
+    environment lookup (four RGBA8 texels).  The scene-stream term belongs to the ray x triangle
+    kernel (the dominant one); image and environment terms to the shade kernel."""
     px = (width // 8 * 8) * (height // 8 * 8)
-    return px * (16 if reset else 32) + (counters["segments"] / 256.0) * scene_bytes(scene) + 16.0 * counters["env_lookups"]
+    scan = (counters["segments"] / 256.0) * scene_bytes(scene)
+    return {"scan": scan, "total": px * (16 if reset else 32) + scan + 16.0 * counters["env_lookups"]}
 
 
 def cpu_baseline(rt, scene, params, width, height, budget_rows=256):
@@ -45,6 +47,7 @@ def cpu_baseline(rt, scene, params, width, height, budget_rows=256):
     import numpy as np
     orc = CpuOracle()
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = min(cores, 16)      # a 1-GPU box's share of the host (the box itself may show hundreds of CPUs)
     dh = height // 8 * 8
     n_strips = max(1, budget_rows // 8)
     stride = max(8, (dh // n_strips) // 8 * 8)
@@ -108,6 +111,7 @@ def main():
     gat = rt.tiling.FrameGatherer(W, H, rank, world, dev, args.strip_rows)
     ctx.bind_device_image(gat.local.data_ptr())          # render straight into the buffer the gather sends
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    ctx.set_option("kernel_timing", 1)                    # HIP events around every launch of the dominant kernel
 
     rnd = sc.GlibcRand(0)
     frame_no = [0]
@@ -128,12 +132,14 @@ def main():
     for _ in range(args.warmup):
         step(next_params())
     timed = [next_params() for _ in range(args.steps)]
-    kernel_ms = 0.0
+    frame_ms = scan_ms = 0.0
+    scan_launches = 0
     barrier()
     t0 = time.perf_counter()
     for p in timed:
         step(p)
-        kernel_ms += ctx.last_frame_ms()                  # HIP events on the launch stream (syncs that frame)
+        t = ctx.last_frame_timing()                       # HIP events on the launch stream (syncs that frame)
+        frame_ms += t["frame_ms"]; scan_ms += t["intersect_ms"]; scan_launches += t["intersect_launches"]
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -155,11 +161,20 @@ def main():
     if rank == 0:
         px = (W // 8 * 8) * (H // 8 * 8)
         paths = px * base.samples * args.steps
-        avg_kernel_s = kernel_ms / 1e3 / args.steps       # rank 0's launches
-        # per-launch algorithmic bytes of rank 0's launch = its share of the frame
+        # dominant kernel = the ray x triangle scan (rank 0's launches; its share of the frame is 1/world)
         share = 1.0 / world
-        alg_bytes = algorithmic_bytes(W, H, cnt, scene) * share
-        alg_flops = cnt["triangle_tests"] * 36.0 * share   # 18 fma per ray-triangle edge evaluation
+        alg = algorithmic_bytes(W, H, cnt, scene)
+        launches_per_frame = max(scan_launches // args.steps, 1)
+        avg_launch_s = scan_ms / 1e3 / max(scan_launches, 1)
+        bytes_per_launch = alg["scan"] * share / launches_per_frame
+        flops_per_launch = cnt["triangle_tests"] * 36.0 * share / launches_per_frame   # 18 fma per edge-function triple
+        kname = {0: "pathtrace_mega_kernel", 1: "bounce_kernel", 2: "intersect_kernel"}[ctx.get_option("kernel")]
+        traffic = None
+        tf = os.path.join(ROOT, "profiles", "hbm_traffic.json")     # written by scripts/gpu_profile.sh (rocprofv3 PMC passes)
+        if os.path.exists(tf):
+            tj = json.load(open(tf))
+            if tj.get("kernel") == kname and tj.get("config") == args.config and world == 1:
+                traffic = tj["hbm_bytes_per_launch"]
         out = {
             "metric": "Mpaths/s at 1920x1080, 8 bounces, 10k tris" if args.config == "C2" else f"Mpaths/s ({args.config})",
             "value": paths / dt / 1e6, "unit": "Mpaths/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -170,13 +185,15 @@ def main():
                                    f"1 spp/frame progressive, dof={base.use_dof}",
                        "parallelism": f"{world} GPU(s), {args.strip_rows}-row strips interleaved, gather to rank 0 every frame",
                        "kernel": ctx.get_option("kernel"), "wf_rays": ctx.get_option("wf_rays"), "wf_mode": ctx.get_option("wf_mode"), "wf_chunk": ctx.get_option("wf_chunk")},
-            "roofline": {"bound": "hbm", "achieved": alg_bytes / avg_kernel_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": alg_bytes / avg_kernel_s / 1e9 / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "pathtrace (per-frame launch)", "avg_launch_ms": avg_kernel_s * 1e3,
-                         "algorithmic_bytes_per_launch": alg_bytes},
-            "valu": {"achieved": alg_flops / avg_kernel_s / 1e12, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": alg_flops / avg_kernel_s / 1e12 / FP32_PEAK_TFLOPS,
-                     "gtests_per_s": cnt["triangle_tests"] * share / avg_kernel_s / 1e9},
+            "roofline": {"bound": "hbm", "achieved": bytes_per_launch / avg_launch_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": bytes_per_launch / avg_launch_s / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": kname, "launches_per_frame": launches_per_frame, "avg_launch_ms": avg_launch_s * 1e3,
+                         "algorithmic_bytes_per_launch": bytes_per_launch,
+                         "note": "brute-force ray x triangle scan is fp32-VALU-bound (see valu); HBM fraction is small by construction"},
+            "valu": {"achieved": flops_per_launch / avg_launch_s / 1e12, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": flops_per_launch / avg_launch_s / 1e12 / FP32_PEAK_TFLOPS,
+                     "gtests_per_s": cnt["triangle_tests"] * share / launches_per_frame / avg_launch_s / 1e9,
+                     "scan_share_of_frame": scan_ms / max(frame_ms, 1e-9)},
             "counters_per_frame": cnt,
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -128,11 +128,21 @@ int rtgl_set_stream(rtgl_context *ctx, void *hip_stream);   /* hipStream_t; NULL
 int rtgl_get_counters(rtgl_context *ctx, rtgl_counters *out);  /* synchronises */
 int rtgl_read_rng_state(rtgl_context *ctx, uint32_t *xyzw);    /* per local pixel final PCG4D state of the last frame; needs option "rng_state"=1 */
 /* keys: "kernel" (enum above), "wf_rays" (rays per lane 1/2/4/8), "wf_mode" (0 scalar-fed, 1 LDS tiles),
- * "wf_chunk" (triangles per work item of the split intersect kernel, multiple of 64), "rng_state", "counters" */
+ * "wf_chunk" (triangles per work item of the split intersect kernel, multiple of 64), "rng_state", "counters",
+ * "kernel_timing" */
 int rtgl_set_option(rtgl_context *ctx, const char *key, int value);
 int rtgl_get_option(rtgl_context *ctx, const char *key, int *value);
 /* elapsed GPU milliseconds of the last rtgl_render_frame (HIP events on the context's stream) */
 int rtgl_last_frame_ms(rtgl_context *ctx, float *ms);
+/* Per-kernel GPU time of the last frame, from HIP events recorded around every launch of the dominant
+ * kernel on the context's stream.  Needs option "kernel_timing"=1 before rendering. */
+typedef struct rtgl_frame_timing {
+    float    frame_ms;            /* whole frame, first launch to last */
+    float    intersect_ms;        /* sum over the ray x triangle kernel launches (the path-trace megakernel when kernel = 0) */
+    uint32_t intersect_launches;
+    uint32_t reserved;
+} rtgl_frame_timing;
+int rtgl_last_frame_timing(rtgl_context *ctx, rtgl_frame_timing *out);
 
 #ifdef __cplusplus
 }

@@ -152,6 +152,8 @@ struct rtgl_context {
     hipStream_t own_stream = nullptr, stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
+    std::vector<hipEvent_t> kev;   // event pairs around the dominant-kernel launches of the current frame
+    uint32_t kev_used = 0;
     std::string error;
 
     // raw scene copies (host) used to rebuild derived buffers
@@ -183,7 +185,7 @@ struct rtgl_context {
     bool tris_dirty = false, visits_dirty = false;
     FrameParams params{};
     bool have_params = false;
-    int opt_kernel = RTGL_KERNEL_WAVEFRONT_SPLIT, opt_rng_state = 0, opt_counters = 0, opt_wf_rays = 4, opt_wf_mode = kLds, opt_wf_chunk = 512;
+    int opt_kernel = RTGL_KERNEL_WAVEFRONT_SPLIT, opt_rng_state = 0, opt_counters = 0, opt_kernel_timing = 0, opt_wf_rays = 4, opt_wf_mode = kLds, opt_wf_chunk = 512;
 };
 
 static int fail(rtgl_context *ctx, int code, const std::string &msg)
@@ -259,6 +261,7 @@ extern "C" void rtgl_destroy(rtgl_context *ctx)
     void *ptrs[] = { ctx->d_spheres, ctx->d_materials, ctx->d_vertices, ctx->d_sphere_visits, ctx->d_edges, ctx->d_planes,
                      ctx->d_env, ctx->d_image_own, ctx->d_rng, ctx->d_counters, ctx->d_u8, ctx->d_group_bounds, ctx->d_wave, ctx->d_counts };
     for (void *p : ptrs) if (p) (void)hipFree(p);
+    for (hipEvent_t e : ctx->kev) (void)hipEventDestroy(e);
     if (ctx->h_counts) (void)hipHostFree(ctx->h_counts);
     if (ctx->counts_ev) (void)hipEventDestroy(ctx->counts_ev);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -405,6 +408,14 @@ static int rebuild_triangles(rtgl_context *ctx)
     return RTGL_OK;
 }
 
+// event pair around one dominant-kernel launch (only with option kernel_timing)
+static void kev_mark(rtgl_context *ctx)
+{
+    if (!ctx->opt_kernel_timing) return;
+    if (ctx->kev_used == ctx->kev.size()) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return; ctx->kev.push_back(e); }
+    (void)hipEventRecord(ctx->kev[ctx->kev_used++], ctx->stream);
+}
+
 // ---- bounce-wavefront pipeline: buffers + launches ------------------------------------------------
 static int ensure_wave_buffers(rtgl_context *ctx, uint32_t n0, uint32_t max_bounce, bool multi_sample)
 {
@@ -493,6 +504,7 @@ static int launch_wavefront(rtgl_context *ctx, const SceneView &sc, const FrameP
             const int key = ctx->opt_wf_mode * 10 + ctx->opt_wf_rays;
             if (ctx->opt_kernel == RTGL_KERNEL_WAVEFRONT_SPLIT) {
                 if (sc.n_tri_visits > 0) {
+                    kev_mark(ctx);
                     switch (key) {
                     case 1: launch_intersect<1, kScalar>(ctx, sc, n0, b); break;
                     case 2: launch_intersect<2, kScalar>(ctx, sc, n0, b); break;
@@ -504,6 +516,7 @@ static int launch_wavefront(rtgl_context *ctx, const SceneView &sc, const FrameP
                     case 18: launch_intersect<8, kLds>(ctx, sc, n0, b); break;
                     default: return fail(ctx, RTGL_ERR_STATE, "unsupported wf_mode / wf_rays combination");
                     }
+                    kev_mark(ctx);
                 }
                 const dim3 shade_grid((estimate_rays(ctx, n0, b) + 255) / 256);
                 if (ctx->opt_counters)
@@ -512,6 +525,7 @@ static int launch_wavefront(rtgl_context *ctx, const SceneView &sc, const FrameP
                     hipLaunchKernelGGL(shade_kernel<false>, shade_grid, dim3(256), 0, ctx->stream, sc, P, im, ctx->wb, b, rng_out, ctx->d_counters);
                 continue;
             }
+            kev_mark(ctx);
             switch (key) {
             case 1: launch_bounce<1, kScalar>(ctx, sc, P, im, n0, b, rng_out); break;
             case 2: launch_bounce<2, kScalar>(ctx, sc, P, im, n0, b, rng_out); break;
@@ -521,6 +535,7 @@ static int launch_wavefront(rtgl_context *ctx, const SceneView &sc, const FrameP
             case 14: launch_bounce<4, kLds>(ctx, sc, P, im, n0, b, rng_out); break;
             default: return fail(ctx, RTGL_ERR_STATE, "unsupported wf_mode / wf_rays combination");
             }
+            kev_mark(ctx);
         }
         HIPCHK(ctx, hipGetLastError());
     }
@@ -579,12 +594,15 @@ extern "C" int rtgl_render_frame(rtgl_context *ctx)
     const bool use_wavefront = ctx->opt_kernel != RTGL_KERNEL_MEGA && P.max_bounce > 0;
     if (use_wavefront && n0 > 0) { int rc = ensure_wave_buffers(ctx, n0, P.max_bounce, P.samples > 1); if (rc) return rc; }
     HIPCHK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+    ctx->kev_used = 0;
     if (n0 > 0 && !use_wavefront) {
         dim3 grid((im.disp_w + 31) / 32, (local_disp_rows + 7) / 8);
+        kev_mark(ctx);
         if (ctx->opt_counters)
             hipLaunchKernelGGL(pathtrace_mega_kernel<true>, grid, dim3(256), 0, ctx->stream, sc, P, im, rng_out, ctx->d_counters);
         else
             hipLaunchKernelGGL(pathtrace_mega_kernel<false>, grid, dim3(256), 0, ctx->stream, sc, P, im, rng_out, ctx->d_counters);
+        kev_mark(ctx);
         HIPCHK(ctx, hipGetLastError());
     } else if (n0 > 0) {
         int rc = launch_wavefront(ctx, sc, P, im, n0, rng_out);
@@ -608,6 +626,22 @@ extern "C" int rtgl_last_frame_ms(rtgl_context *ctx, float *ms)
     if (!ms || !ctx->timed) return fail(ctx, RTGL_ERR_STATE, "no frame has been rendered");
     HIPCHK(ctx, hipEventSynchronize(ctx->ev1));
     HIPCHK(ctx, hipEventElapsedTime(ms, ctx->ev0, ctx->ev1));
+    return RTGL_OK;
+}
+
+extern "C" int rtgl_last_frame_timing(rtgl_context *ctx, rtgl_frame_timing *out)
+{
+    ENTER(ctx);
+    if (!out || !ctx->timed) return fail(ctx, RTGL_ERR_STATE, "no frame has been rendered");
+    if (!ctx->opt_kernel_timing) return fail(ctx, RTGL_ERR_STATE, "option kernel_timing was not enabled before rendering");
+    memset(out, 0, sizeof *out);
+    HIPCHK(ctx, hipEventSynchronize(ctx->ev1));
+    HIPCHK(ctx, hipEventElapsedTime(&out->frame_ms, ctx->ev0, ctx->ev1));
+    for (uint32_t i = 0; i + 1 < ctx->kev_used; i += 2) {
+        float ms = 0.0f;
+        HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->kev[i], ctx->kev[i + 1]));
+        out->intersect_ms += ms; out->intersect_launches++;
+    }
     return RTGL_OK;
 }
 
@@ -720,6 +754,7 @@ extern "C" int rtgl_set_option(rtgl_context *ctx, const char *key, int value)
         ctx->opt_wf_mode = value;
     } else if (!strcmp(key, "rng_state")) ctx->opt_rng_state = value != 0;
     else if (!strcmp(key, "counters")) ctx->opt_counters = value != 0;
+    else if (!strcmp(key, "kernel_timing")) ctx->opt_kernel_timing = value != 0;
     else return fail(ctx, RTGL_ERR_INVALID, std::string("unknown option ") + key);
     return RTGL_OK;
 }
@@ -734,6 +769,7 @@ extern "C" int rtgl_get_option(rtgl_context *ctx, const char *key, int *value)
     else if (!strcmp(key, "wf_chunk")) *value = ctx->opt_wf_chunk;
     else if (!strcmp(key, "rng_state")) *value = ctx->opt_rng_state;
     else if (!strcmp(key, "counters")) *value = ctx->opt_counters;
+    else if (!strcmp(key, "kernel_timing")) *value = ctx->opt_kernel_timing;
     else return fail(ctx, RTGL_ERR_INVALID, std::string("unknown option ") + key);
     return RTGL_OK;
 }

@@ -27,7 +27,7 @@ ABI_SYMBOLS = [
     "rtgl_synchronize", "rtgl_read_image_f32", "rtgl_read_image_u8", "rtgl_write_image_f32",
     "rtgl_clear_image", "rtgl_local_rows", "rtgl_local_row_to_global", "rtgl_device_image",
     "rtgl_bind_device_image", "rtgl_set_stream", "rtgl_get_counters", "rtgl_read_rng_state",
-    "rtgl_set_option", "rtgl_get_option", "rtgl_last_frame_ms",
+    "rtgl_set_option", "rtgl_get_option", "rtgl_last_frame_ms", "rtgl_last_frame_timing",
 ]
 
 
@@ -48,6 +48,11 @@ class CCounters(C.Structure):
     """rtgl_counters"""
     _fields_ = [("paths", C.c_uint64), ("segments", C.c_uint64), ("triangle_tests", C.c_uint64),
                 ("candidates", C.c_uint64), ("env_lookups", C.c_uint64), ("reserved", C.c_uint64 * 3)]
+
+
+class CFrameTiming(C.Structure):
+    """rtgl_frame_timing"""
+    _fields_ = [("frame_ms", C.c_float), ("intersect_ms", C.c_float), ("intersect_launches", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 def build_library(force: bool = False) -> str:
@@ -94,6 +99,7 @@ def load_library() -> C.CDLL:
     L.rtgl_set_option.argtypes = [vp, C.c_char_p, i]
     L.rtgl_get_option.argtypes = [vp, C.c_char_p, C.POINTER(i)]
     L.rtgl_last_frame_ms.argtypes = [vp, C.POINTER(C.c_float)]
+    L.rtgl_last_frame_timing.argtypes = [vp, C.POINTER(CFrameTiming)]
     _lib = L
     return L
 
@@ -189,6 +195,11 @@ class Context:
         ms = C.c_float()
         self._chk(self.lib.rtgl_last_frame_ms(self.h, C.byref(ms)))
         return float(ms.value)
+
+    def last_frame_timing(self) -> dict:
+        t = CFrameTiming()
+        self._chk(self.lib.rtgl_last_frame_timing(self.h, C.byref(t)))
+        return dict(frame_ms=float(t.frame_ms), intersect_ms=float(t.intersect_ms), intersect_launches=int(t.intersect_launches))
 
     # --- image
     def read_image(self) -> np.ndarray:

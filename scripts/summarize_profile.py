@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""Turns a gpurun_out/prof_<tag>/ directory (written by scripts/gpu_profile.sh on the GPU box) into the
+tracked summaries under profiles/<tag>/ and, for the dominant kernel, profiles/hbm_traffic.json.
+
+HBM traffic follows MI355X_MICROARCH.md (HBM / rocprofv3 section): FETCH_SIZE and WRITE_SIZE are
+collected in separate --pmc passes, both are in KiB, and on gfx950 FETCH_SIZE reports exactly half of
+the bytes of wide (16 B/lane) coalesced streaming reads -- which is what the scan kernel issues for its
+ray and triangle-tile loads -- so the read side is doubled; WRITE_SIZE is exact."""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+tag, config = sys.argv[1], (sys.argv[2] if len(sys.argv) > 2 else "C2")
+src, dst = f"gpurun_out/prof_{tag}", f"profiles/{tag}"
+os.makedirs(dst, exist_ok=True)
+shutil.copy(glob.glob(f"{src}/trace/runc/*_kernel_stats.csv")[0], f"{dst}/kernel_stats.csv")
+shutil.copy(f"{src}/bench_trace.json", f"{dst}/bench_under_rocprof.json")
+out = {}
+for sub in ("pmc_sq", "pmc_fetch", "pmc_write"):
+    f = glob.glob(f"{src}/{sub}/runc/*_counter_collection.csv")[0]
+    agg = collections.defaultdict(lambda: collections.defaultdict(float))
+    dur, calls, seen = collections.defaultdict(float), collections.Counter(), set()
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"].split("(")[0]
+        agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
+        if r["Dispatch_Id"] not in seen:
+            seen.add(r["Dispatch_Id"]); dur[k] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"]); calls[k] += 1
+    out[sub] = {k: dict(calls=calls[k], total_ms=dur[k] / 1e6, **v) for k, v in agg.items() if "rt::" in k or "pathtrace" in k}
+json.dump(out, open(f"{dst}/pmc_summary.json", "w"), indent=1)
+# dominant kernel (largest total time in the kernel-trace stats)
+stats = list(csv.DictReader(open(f"{dst}/kernel_stats.csv")))
+dom = max(stats, key=lambda r: float(r["TotalDurationNs"]))["Name"].split("(")[0]
+short = "intersect_kernel" if "intersect_kernel" in dom else "bounce_kernel" if "bounce_kernel" in dom else "pathtrace_mega_kernel"
+fetch = sum(v["FETCH_SIZE"] for k, v in out["pmc_fetch"].items() if short in k)
+fcalls = sum(v["calls"] for k, v in out["pmc_fetch"].items() if short in k)
+write = sum(v["WRITE_SIZE"] for k, v in out["pmc_write"].items() if short in k)
+wcalls = sum(v["calls"] for k, v in out["pmc_write"].items() if short in k)
+traffic = fetch * 1024 * 2 / max(fcalls, 1) + write * 1024 / max(wcalls, 1)
+json.dump({"kernel": short, "config": config, "profile": dst, "hbm_bytes_per_launch": traffic,
+           "fetch_kib_per_launch_raw": fetch / max(fcalls, 1), "write_kib_per_launch": write / max(wcalls, 1),
+           "correction": "FETCH_SIZE x2 (gfx950, wide coalesced reads), WRITE_SIZE exact; separate PMC passes"},
+          open("profiles/hbm_traffic.json", "w"), indent=1)
+print(open("profiles/hbm_traffic.json").read())
+for r in stats[:6]:
+    print(r["Name"][:70], r["Calls"], "avg_us", float(r["AverageNs"]) / 1e3)
