@@ -166,6 +166,7 @@ public:
             m_reset = false;
             m_time = 0; m_frames = 0;
         }
+        m_last_params = p;
         check(rtgl_set_frame_params(m_ctx, &p));
         check(rtgl_render_frame(m_ctx));
     }
@@ -287,6 +288,7 @@ public:
     void set_background(const glm::vec3 &c) { m_background = c; }
     Camera &camera() { return m_camera; }
     rtgl_context *context() { return m_ctx; }
+    const rtgl_frame_params &last_frame_params() const { return m_last_params; }   // what the last render() uploaded
 
     // 8-bit, clamped, vertically flipped PNG named render_<W>x<H>_<unixtime>_<frames>.png (src/renderer.cpp:218-245)
     void save_to_file() const
@@ -312,6 +314,7 @@ private:
     void check(int rc) const { if (rc != RTGL_OK) std::cerr << "rtgl: " << rtgl_last_error(m_ctx) << std::endl; }
 
     rtgl_context *m_ctx = nullptr;
+    rtgl_frame_params m_last_params{};
     std::unique_ptr<CubemapTexture> m_envmap = nullptr;
     int m_bounces = 5;
     unsigned int m_samples = 1;

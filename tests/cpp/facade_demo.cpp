@@ -26,7 +26,7 @@ int main(int argc, char **argv)
 
     srand(0);
     Renderer renderer(width, height);
-    if (!renderer.context()) return 3;
+    const bool have_device = renderer.context() != nullptr;      // without a device: still dump the marshalled inputs
 
     const float r = 10000, room = 16.0f, sr = 4.0f;
     const std::vector<Sphere> spheres = {
@@ -47,6 +47,7 @@ int main(int argc, char **argv)
         Material(gfx::rgb(0xAAAAAA), gfx::rgb(0x0), 0.5f, MaterialType::SPECULAR),
     };
     renderer.set_materials(materials);
+    dump(dir + "/materials.raw", materials.data(), materials.size() * sizeof(Material));
 
     // spheres through the reference's own route for visible spheres: a kd-tree over them
     renderer.set_kdtree(spheres);
@@ -69,9 +70,15 @@ int main(int argc, char **argv)
     dump(dir + "/vertices.raw", obj.data(), obj.size() * sizeof(glm::vec4));
 
     const std::array<std::string, 6> faces = {dir + "/right.png", dir + "/left.png", dir + "/top.png", dir + "/bottom.png", dir + "/front.png", dir + "/back.png"};
+    {
+        CubemapTexture probe(faces);
+        dump(dir + "/envmap.raw", probe.data.data(), probe.data.size());
+    }
     renderer.set_envmap(std::make_unique<CubemapTexture>(faces));
+    if (!have_device) return 3;
 
     renderer.set_bounces(6);
+    std::vector<rtgl_frame_params> used;
     for (int f = 1; f <= frames; ++f) {
         if (f == reset_at) {                      // what pressing 'r' does in the reference (src/renderer.cpp:365-367)
             SDL_Event e{};
@@ -82,7 +89,9 @@ int main(int argc, char **argv)
         }
         renderer.set_frame_budget(1);
         renderer.run();                           // one loop iteration: m_frames++, events, render
+        used.push_back(renderer.last_frame_params());
     }
+    dump(dir + "/params.raw", used.data(), used.size() * sizeof(rtgl_frame_params));
     std::vector<float> img = renderer.read_image();
     if (!dump(dir + "/image.raw", img.data(), img.size() * sizeof(float))) return 4;
     if (argc > 6) renderer.save_to_file();

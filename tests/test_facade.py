@@ -78,12 +78,20 @@ def test_facade_program_matches_oracle(tmp_path, rt, oracle):
     scene = sc.Scene(spheres=np.fromfile(os.path.join(d, "spheres.raw"), np.float32).reshape(-1, 8),
                      materials=sc.demo_materials(), meshes=sc.make_meshes([(0, verts.shape[0] // 3, 6)]), vertices=verts,
                      nodes=np.fromfile(os.path.join(d, "nodes.raw"), np.float32).reshape(-1, 12), env=env)
-    loop = rt.host.FrameLoop(sc.FrameParams(max_bounce=6))
+    # the uniforms the facade uploaded each frame (u_random is libc rand(), whose stream other libraries in the
+    # process may also draw from, so the values are taken from the program rather than assumed)
+    import ctypes
+    raw = open(os.path.join(d, "params.raw"), "rb").read()
+    n = ctypes.sizeof(rt.host.CFrameParams)
+    used = [rt.host.CFrameParams.from_buffer_copy(raw[i * n:(i + 1) * n]) for i in range(frames)]
+    assert [(u.frames, u.reset_flag) for u in used] == [(1, 0), (2, 0), (3, 0), (4, 1), (1, 0), (2, 0)]   # renderer.cpp:98,123-127
+    defaults = sc.FrameParams()
     want = np.zeros((H, W, 4), np.float32)
-    for f in range(1, frames + 1):
-        if f == reset_at:
-            loop.reset_buffer()
-        oracle.render(scene, loop.next_frame(), want, threads=4)
+    for u in used:
+        assert u.max_bounce == 6 and u.samples == 1 and u.use_dof == 1 and u.use_envmap == 1
+        assert np.float32(u.camera_fov) == np.float32(defaults.camera_fov) and tuple(u.camera_right) == (-1.0, 0.0, 0.0)
+        p = defaults.replace(frames=u.frames, random=u.random, reset_flag=u.reset_flag, max_bounce=u.max_bounce)
+        oracle.render(scene, p, want, threads=4)
     assert (got.view(np.uint32) == want.view(np.uint32)).all()
     # save_to_file: render_<W>x<H>_<time>_<frames>.png, flipped, 8-bit
     pngs = [f for f in os.listdir(d) if f.startswith(f"render_{W}x{H}_") and f.endswith(".png")]
