@@ -364,15 +364,96 @@ struct ScanRays {
 constexpr int kCandSlots = 16;          // parked candidates per lane per work item
 constexpr uint32_t kMaxChunk = 4096;    // candidate entry = ray (4 bits) << 12 | triangle offset in chunk (12 bits)
 
-template <int R>
+// Two rays per instruction: v_pk_fma_f32 evaluates the same fma chain for a pair of rays with the triangle
+// coefficient broadcast through op_sel, halving the instructions issued per test (the plain v_fma_f32
+// stream is issue-limited at ~2.4 cycles per wave-instruction, tools/valu_rate.hip).  Each half is an
+// ordinary IEEE fma, so the filter values are the ones filter_min() computes.
+typedef float f2 __attribute__((ext_vector_type(2)));
+struct RayPair { f2 cvx, cvy, cvz, dx, dy, dz; };
+
+__device__ __forceinline__ f2 bc(float c) { return f2{c, c}; }
+__device__ __forceinline__ f2 edge_chain2(float ex, float ey, float ez, float mx, float my, float mz, const RayPair &p)
+{
+    f2 f = bc(ex) * p.cvx;
+    f = __builtin_elementwise_fma(bc(ey), p.cvy, f); f = __builtin_elementwise_fma(bc(ez), p.cvz, f);
+    f = __builtin_elementwise_fma(bc(mx), p.dx, f);  f = __builtin_elementwise_fma(bc(my), p.dy, f);
+    f = __builtin_elementwise_fma(bc(mz), p.dz, f);
+    return f;
+}
+__device__ __forceinline__ f2 filter_min2(const TriCoef &T, const RayPair &p)
+{
+    f2 f0 = edge_chain2(T.q0.x, T.q0.y, T.q0.z, T.q2.y, T.q2.z, T.q2.w, p);
+    f2 f1 = edge_chain2(T.q0.w, T.q1.x, T.q1.y, T.q3.x, T.q3.y, T.q3.z, p);
+    f2 f2_ = edge_chain2(T.q1.z, T.q1.w, T.q2.x, T.q3.w, T.q4.x, T.q4.y, p);
+    return __builtin_elementwise_min(__builtin_elementwise_min(f0, f1), f2_);
+}
+
+// one edge function: dot(e_k, cv) + dot(m_k, d) as a single fma chain
+__device__ __forceinline__ float edge_chain(float ex, float ey, float ez, float mx, float my, float mz, f3 cv, f3 d)
+{
+    float f = ex * cv.x;
+    f = __builtin_fmaf(ey, cv.y, f); f = __builtin_fmaf(ez, cv.z, f);
+    f = __builtin_fmaf(mx, d.x, f);  f = __builtin_fmaf(my, d.y, f);  f = __builtin_fmaf(mz, d.z, f);
+    return f;
+}
+
+// EARLY = wave-level short circuit (the SIMD form of the reference's `&&` between the three edge tests,
+// :243-245): if no ray of the wave can pass edge 0 the other two edges are not evaluated, likewise after
+// edge 1.  Pays off when the rays of a wave are coherent (camera rays: bounce 0), costs a few percent when
+// they are not, so the host enables it per bounce.
+template <int R, bool EARLY>
 __device__ __forceinline__ void scan_triangle(const TriCoef &T, const ScanRays<R> &sr, uint32_t off, uint16_t *cand, uint32_t &n_cand)
 {
+    if (!EARLY && (R % 2) == 0) {
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-        float mn = filter_min(T, sr.cv[r], sr.d[r]);
-        if (!(mn <= sr.thresh[r])) {                                     // rare
-            if (n_cand < (uint32_t)kCandSlots) cand[n_cand * 256u] = (uint16_t)((r << 12) | off);
-            n_cand++;                                                    // > kCandSlots marks overflow
+        for (int q = 0; q < R / 2; ++q) {
+            RayPair p;
+            p.cvx = f2{sr.cv[2 * q].x, sr.cv[2 * q + 1].x}; p.cvy = f2{sr.cv[2 * q].y, sr.cv[2 * q + 1].y}; p.cvz = f2{sr.cv[2 * q].z, sr.cv[2 * q + 1].z};
+            p.dx = f2{sr.d[2 * q].x, sr.d[2 * q + 1].x}; p.dy = f2{sr.d[2 * q].y, sr.d[2 * q + 1].y}; p.dz = f2{sr.d[2 * q].z, sr.d[2 * q + 1].z};
+            const f2 mn = filter_min2(T, p);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int r = 2 * q + h;
+                if (!((h ? mn.y : mn.x) <= sr.thresh[r])) {                  // rare
+                    if (n_cand < (uint32_t)kCandSlots) cand[n_cand * 256u] = (uint16_t)((r << 12) | off);
+                    n_cand++;                                                // > kCandSlots marks overflow
+                }
+            }
+        }
+    } else if (!EARLY) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            float mn = filter_min(T, sr.cv[r], sr.d[r]);
+            if (!(mn <= sr.thresh[r])) {
+                if (n_cand < (uint32_t)kCandSlots) cand[n_cand * 256u] = (uint16_t)((r << 12) | off);
+                n_cand++;
+            }
+        }
+    } else {
+        float mn[R];
+        unsigned long long any = 0;                                         // wave masks: v_cmp -> SGPR pair, s_or_b64
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            mn[r] = edge_chain(T.q0.x, T.q0.y, T.q0.z, T.q2.y, T.q2.z, T.q2.w, sr.cv[r], sr.d[r]);
+            any |= __builtin_amdgcn_ballot_w64(!(mn[r] <= sr.thresh[r]));
+        }
+        if (any) {
+            any = 0;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                mn[r] = __builtin_fminf(mn[r], edge_chain(T.q0.w, T.q1.x, T.q1.y, T.q3.x, T.q3.y, T.q3.z, sr.cv[r], sr.d[r]));
+                any |= __builtin_amdgcn_ballot_w64(!(mn[r] <= sr.thresh[r]));
+            }
+            if (any) {
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    mn[r] = __builtin_fminf(mn[r], edge_chain(T.q1.z, T.q1.w, T.q2.x, T.q3.w, T.q4.x, T.q4.y, sr.cv[r], sr.d[r]));
+                    if (!(mn[r] <= sr.thresh[r])) {
+                        if (n_cand < (uint32_t)kCandSlots) cand[n_cand * 256u] = (uint16_t)((r << 12) | off);
+                        n_cand++;
+                    }
+                }
+            }
         }
     }
 }
@@ -385,7 +466,7 @@ __device__ __forceinline__ void exact_and_merge(const SceneView &sc, const RayQu
     if (kEps < t && t < kInf) atomicMin(&best[slot], ((unsigned long long)__float_as_uint(t) << 32) | v);
 }
 
-template <int R, int MODE, bool kCount>
+template <int R, int MODE, bool EARLY, bool kCount>
 __global__ void __launch_bounds__(256) intersect_kernel(SceneView sc, WaveBuffers wb, uint32_t bounce, uint32_t chunk_tris, Counters *counters)
 {
     __shared__ float4 lds_tile[MODE == kLds ? kTile * 5 : 1];
@@ -426,7 +507,7 @@ __global__ void __launch_bounds__(256) intersect_kernel(SceneView sc, WaveBuffer
             const uint32_t v1 = min(v0 + (uint32_t)kBoundGroup, v_end);
 #pragma unroll 2
             for (uint32_t v = v0; v < v1; ++v)
-                scan_triangle<R>(load_coef(src + (size_t)v * 5), sr, v - v_begin, cand, n_cand);
+                scan_triangle<R, EARLY>(load_coef(src + (size_t)v * 5), sr, v - v_begin, cand, n_cand);
         }
     } else {
         // tiles of kTile records: HBM -> LDS with coalesced 16-byte loads (thread i moves float4 i, i+256, ...),
@@ -453,7 +534,7 @@ __global__ void __launch_bounds__(256) intersect_kernel(SceneView sc, WaveBuffer
 #pragma unroll 2
                 for (uint32_t j = j0; j < j1; ++j) {
                     TriCoef nxt_coef = load_coef(lds_tile + min(j + 1u, (uint32_t)kTile - 1u) * 5);
-                    scan_triangle<R>(cur, sr, vbase - v_begin + j, cand, n_cand);
+                    scan_triangle<R, EARLY>(cur, sr, vbase - v_begin + j, cand, n_cand);
                     cur = nxt_coef;
                 }
             }

@@ -185,7 +185,7 @@ struct rtgl_context {
     bool tris_dirty = false, visits_dirty = false;
     FrameParams params{};
     bool have_params = false;
-    int opt_kernel = RTGL_KERNEL_WAVEFRONT_SPLIT, opt_rng_state = 0, opt_counters = 0, opt_kernel_timing = 0, opt_wf_rays = 4, opt_wf_mode = kLds, opt_wf_chunk = 512;
+    int opt_kernel = RTGL_KERNEL_WAVEFRONT_SPLIT, opt_rng_state = 0, opt_counters = 0, opt_kernel_timing = 0, opt_wf_rays = 4, opt_wf_mode = kLds, opt_wf_chunk = 512, opt_wf_early = 0;
 };
 
 static int fail(rtgl_context *ctx, int code, const std::string &msg)
@@ -481,10 +481,11 @@ static void launch_intersect(rtgl_context *ctx, const SceneView &sc, uint32_t n0
     const uint32_t chunk = (uint32_t)ctx->opt_wf_chunk;
     const uint32_t est = estimate_rays(ctx, n0, bounce);
     dim3 grid((est + 256u * R - 1) / (256u * R), (sc.n_tri_visits + chunk - 1) / chunk);
-    if (ctx->opt_counters)
-        hipLaunchKernelGGL((intersect_kernel<R, MODE, true>), grid, dim3(256), 0, ctx->stream, sc, ctx->wb, bounce, chunk, ctx->d_counters);
-    else
-        hipLaunchKernelGGL((intersect_kernel<R, MODE, false>), grid, dim3(256), 0, ctx->stream, sc, ctx->wb, bounce, chunk, ctx->d_counters);
+    const bool early = bounce < (uint32_t)ctx->opt_wf_early;     // wave-level edge short circuit on the coherent bounces
+#define RTGL_LAUNCH_ISECT(E, C) hipLaunchKernelGGL((intersect_kernel<R, MODE, E, C>), grid, dim3(256), 0, ctx->stream, sc, ctx->wb, bounce, chunk, ctx->d_counters)
+    if (early) { if (ctx->opt_counters) RTGL_LAUNCH_ISECT(true, true); else RTGL_LAUNCH_ISECT(true, false); }
+    else { if (ctx->opt_counters) RTGL_LAUNCH_ISECT(false, true); else RTGL_LAUNCH_ISECT(false, false); }
+#undef RTGL_LAUNCH_ISECT
 }
 
 static int launch_wavefront(rtgl_context *ctx, const SceneView &sc, const FrameParams &P, const ImageView &im, uint32_t n0, uint4 *rng_out)
@@ -749,6 +750,9 @@ extern "C" int rtgl_set_option(rtgl_context *ctx, const char *key, int value)
     } else if (!strcmp(key, "wf_chunk")) {
         if (value < kBoundGroup || value % kBoundGroup || (uint32_t)value > kMaxChunk) return fail(ctx, RTGL_ERR_INVALID, "wf_chunk must be a multiple of 64 in [64, 4096]");
         ctx->opt_wf_chunk = value;
+    } else if (!strcmp(key, "wf_early")) {
+        if (value < 0) return fail(ctx, RTGL_ERR_INVALID, "wf_early is the number of leading bounces with the wave-level edge short circuit (>= 0)");
+        ctx->opt_wf_early = value;
     } else if (!strcmp(key, "wf_mode")) {
         if (value != kScalar && value != kLds) return fail(ctx, RTGL_ERR_INVALID, "wf_mode must be 0 (scalar) or 1 (lds)");
         ctx->opt_wf_mode = value;
@@ -767,6 +771,7 @@ extern "C" int rtgl_get_option(rtgl_context *ctx, const char *key, int *value)
     else if (!strcmp(key, "wf_rays")) *value = ctx->opt_wf_rays;
     else if (!strcmp(key, "wf_mode")) *value = ctx->opt_wf_mode;
     else if (!strcmp(key, "wf_chunk")) *value = ctx->opt_wf_chunk;
+    else if (!strcmp(key, "wf_early")) *value = ctx->opt_wf_early;
     else if (!strcmp(key, "rng_state")) *value = ctx->opt_rng_state;
     else if (!strcmp(key, "counters")) *value = ctx->opt_counters;
     else if (!strcmp(key, "kernel_timing")) *value = ctx->opt_kernel_timing;

@@ -17,6 +17,8 @@ def run_both(rt, oracle, scene, params, W, H, frames=1, rng_state=True, reset_at
     if variant is not None:
         ctx.set_option("kernel", variant[0]); ctx.set_option("wf_mode", variant[1]); ctx.set_option("wf_rays", variant[2])
         ctx.set_option("wf_chunk", 128)      # small chunks so that even the small test meshes span several work items
+        if len(variant) > 3:
+            ctx.set_option("wf_early", variant[3])
     if rng_state:
         ctx.set_option("rng_state", 1)
     ctx.set_option("counters", 1)
@@ -55,6 +57,16 @@ def test_variants_mesh_env(rt, oracle, variant):
     r = run_both(rt, oracle, sc.scene_mesh(30, 10, env_size=32), sc.params_c2(), 136, 72, frames=2, variant=variant)
     assert_bit_exact(r, 136, 72)
     assert r["cnt_g"]["triangle_tests"] == r["cnt_o"]["triangle_tests"]
+
+
+@pytest.mark.parametrize("early", [0, 1, 8])
+@pytest.mark.parametrize("variant", [(2, 1, 4), (2, 0, 2), (2, 1, 1)])
+def test_wave_level_edge_short_circuit(rt, oracle, variant, early):
+    """wf_early = number of leading bounces that use the wave-level short circuit of the three edge tests."""
+    sc = rt.scenes
+    ctx_opts = variant + (early,)
+    r = run_both(rt, oracle, sc.scene_mesh(30, 10, env_size=32), sc.params_c2(), 136, 72, frames=2, variant=ctx_opts)
+    assert_bit_exact(r, 136, 72)
 
 
 @pytest.mark.parametrize("variant", [(0, 0, 1), (1, 1, 2), (2, 1, 4), (2, 0, 8)])
