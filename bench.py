@@ -77,6 +77,8 @@ def main():
     ap.add_argument("--wf-early", type=int, default=None, help="leading bounces with the wave-level edge short circuit")
     ap.add_argument("--strip-rows", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sync-each-frame", action="store_true", help="diagnostic: host waits for every frame")
+    ap.add_argument("--no-kernel-timing", action="store_true", help="diagnostic: no HIP events around the scan launches")
     ap.add_argument("--cpu-rows", type=int, default=256)
     args = ap.parse_args()
 
@@ -112,7 +114,7 @@ def main():
     gat = rt.tiling.FrameGatherer(W, H, rank, world, dev, args.strip_rows)
     ctx.bind_device_image(gat.local.data_ptr())          # render straight into the buffer the gather sends
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
-    ctx.set_option("kernel_timing", 1)                    # HIP events around every launch of the dominant kernel
+    ctx.set_option("kernel_timing", 0 if args.no_kernel_timing else 1)   # HIP events around every launch of the dominant kernel
 
     rnd = sc.GlibcRand(0)
     frame_no = [0]
@@ -133,16 +135,21 @@ def main():
     for _ in range(args.warmup):
         step(next_params())
     timed = [next_params() for _ in range(args.steps)]
-    frame_ms = scan_ms = 0.0
-    scan_launches = 0
     barrier()
+    ctx.timing_reset()
     t0 = time.perf_counter()
-    for p in timed:
+    for p in timed:                                       # frames are queued back to back: no host sync inside the region
         step(p)
-        t = ctx.last_frame_timing()                       # HIP events on the launch stream (syncs that frame)
-        frame_ms += t["frame_ms"]; scan_ms += t["intersect_ms"]; scan_launches += t["intersect_launches"]
+        if args.sync_each_frame:
+            ctx.synchronize()
     barrier()
     dt = time.perf_counter() - t0
+    if args.no_kernel_timing:
+        frame_ms, scan_ms, scan_launches = dt * 1e3, dt * 1e3, args.steps * base.max_bounce
+    else:
+        t = ctx.accumulated_timing()                      # HIP events recorded on the launch stream around every scan launch
+        frame_ms, scan_ms, scan_launches = t["frame_ms"], t["intersect_ms"], t["intersect_launches"]
+        assert t["frames"] == args.steps
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -166,7 +173,7 @@ def main():
         share = 1.0 / world
         alg = algorithmic_bytes(W, H, cnt, scene)
         launches_per_frame = max(scan_launches // args.steps, 1)
-        avg_launch_s = scan_ms / 1e3 / max(scan_launches, 1)
+        avg_launch_s = max(scan_ms, 1e-9) / 1e3 / max(scan_launches, 1)     # (a scene without triangles has no scan launches)
         bytes_per_launch = alg["scan"] * share / launches_per_frame
         flops_per_launch = cnt["triangle_tests"] * 36.0 * share / launches_per_frame   # 18 fma per edge-function triple
         kname = {0: "pathtrace_mega_kernel", 1: "bounce_kernel", 2: "intersect_kernel"}[ctx.get_option("kernel")]

@@ -144,6 +144,11 @@ typedef struct rtgl_frame_timing {
     uint32_t reserved;
 } rtgl_frame_timing;
 int rtgl_last_frame_timing(rtgl_context *ctx, rtgl_frame_timing *out);
+/* Same figures summed over every frame rendered since the last rtgl_timing_reset (or since "kernel_timing"
+ * was enabled): lets a caller keep frames queued back to back and read the HIP-event times once at the
+ * end.  frames_out (may be NULL) receives the number of frames covered.  Synchronises. */
+int rtgl_accumulated_timing(rtgl_context *ctx, rtgl_frame_timing *out, uint32_t *frames_out);
+int rtgl_timing_reset(rtgl_context *ctx);
 
 #ifdef __cplusplus
 }

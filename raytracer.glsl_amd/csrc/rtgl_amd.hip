@@ -152,8 +152,10 @@ struct rtgl_context {
     hipStream_t own_stream = nullptr, stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
-    std::vector<hipEvent_t> kev;   // event pairs around the dominant-kernel launches of the current frame
+    // kernel_timing: events since the last rtgl_timing_reset.  Per frame: [frame begin, (launch begin, launch end)*, frame end]
+    std::vector<hipEvent_t> kev;
     uint32_t kev_used = 0;
+    std::vector<uint32_t> kev_frame_start;   // index into kev of each recorded frame's first event
     std::string error;
 
     // raw scene copies (host) used to rebuild derived buffers
@@ -595,7 +597,11 @@ extern "C" int rtgl_render_frame(rtgl_context *ctx)
     const bool use_wavefront = ctx->opt_kernel != RTGL_KERNEL_MEGA && P.max_bounce > 0;
     if (use_wavefront && n0 > 0) { int rc = ensure_wave_buffers(ctx, n0, P.max_bounce, P.samples > 1); if (rc) return rc; }
     HIPCHK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
-    ctx->kev_used = 0;
+    if (ctx->opt_kernel_timing) {
+        if (ctx->kev_frame_start.size() >= 4096) { ctx->kev_used = 0; ctx->kev_frame_start.clear(); }   // bounded history
+        ctx->kev_frame_start.push_back(ctx->kev_used);
+        kev_mark(ctx);                                   // frame begin
+    }
     if (n0 > 0 && !use_wavefront) {
         dim3 grid((im.disp_w + 31) / 32, (local_disp_rows + 7) / 8);
         kev_mark(ctx);
@@ -610,6 +616,7 @@ extern "C" int rtgl_render_frame(rtgl_context *ctx)
         if (rc) return rc;
     }
     HIPCHK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+    kev_mark(ctx);                                       // frame end
     ctx->timed = true;
     return RTGL_OK;
 }
@@ -630,19 +637,48 @@ extern "C" int rtgl_last_frame_ms(rtgl_context *ctx, float *ms)
     return RTGL_OK;
 }
 
+// sums the event pairs of frames [first, last) of the recorded history
+static int sum_timing(rtgl_context *ctx, size_t first, size_t last, rtgl_frame_timing *out)
+{
+    memset(out, 0, sizeof *out);
+    for (size_t f = first; f < last; ++f) {
+        const uint32_t b = ctx->kev_frame_start[f], e = (f + 1 < ctx->kev_frame_start.size()) ? ctx->kev_frame_start[f + 1] : ctx->kev_used;
+        if (e < b + 2) continue;
+        float ms = 0.0f;
+        HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->kev[b], ctx->kev[e - 1]));
+        out->frame_ms += ms;
+        for (uint32_t i = b + 1; i + 1 < e - 1; i += 2) {
+            HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->kev[i], ctx->kev[i + 1]));
+            out->intersect_ms += ms; out->intersect_launches++;
+        }
+    }
+    return RTGL_OK;
+}
+
 extern "C" int rtgl_last_frame_timing(rtgl_context *ctx, rtgl_frame_timing *out)
 {
     ENTER(ctx);
     if (!out || !ctx->timed) return fail(ctx, RTGL_ERR_STATE, "no frame has been rendered");
-    if (!ctx->opt_kernel_timing) return fail(ctx, RTGL_ERR_STATE, "option kernel_timing was not enabled before rendering");
-    memset(out, 0, sizeof *out);
-    HIPCHK(ctx, hipEventSynchronize(ctx->ev1));
-    HIPCHK(ctx, hipEventElapsedTime(&out->frame_ms, ctx->ev0, ctx->ev1));
-    for (uint32_t i = 0; i + 1 < ctx->kev_used; i += 2) {
-        float ms = 0.0f;
-        HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->kev[i], ctx->kev[i + 1]));
-        out->intersect_ms += ms; out->intersect_launches++;
-    }
+    if (!ctx->opt_kernel_timing || ctx->kev_frame_start.empty()) return fail(ctx, RTGL_ERR_STATE, "option kernel_timing was not enabled before rendering");
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return sum_timing(ctx, ctx->kev_frame_start.size() - 1, ctx->kev_frame_start.size(), out);
+}
+
+extern "C" int rtgl_accumulated_timing(rtgl_context *ctx, rtgl_frame_timing *out, uint32_t *frames_out)
+{
+    ENTER(ctx);
+    if (!out) return fail(ctx, RTGL_ERR_INVALID, "out is NULL");
+    if (!ctx->opt_kernel_timing) return fail(ctx, RTGL_ERR_STATE, "option kernel_timing is not enabled");
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (frames_out) *frames_out = (uint32_t)ctx->kev_frame_start.size();
+    return sum_timing(ctx, 0, ctx->kev_frame_start.size(), out);
+}
+
+extern "C" int rtgl_timing_reset(rtgl_context *ctx)
+{
+    ENTER(ctx);
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->kev_used = 0; ctx->kev_frame_start.clear();
     return RTGL_OK;
 }
 
@@ -758,8 +794,10 @@ extern "C" int rtgl_set_option(rtgl_context *ctx, const char *key, int value)
         ctx->opt_wf_mode = value;
     } else if (!strcmp(key, "rng_state")) ctx->opt_rng_state = value != 0;
     else if (!strcmp(key, "counters")) ctx->opt_counters = value != 0;
-    else if (!strcmp(key, "kernel_timing")) ctx->opt_kernel_timing = value != 0;
-    else return fail(ctx, RTGL_ERR_INVALID, std::string("unknown option ") + key);
+    else if (!strcmp(key, "kernel_timing")) {
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        ctx->opt_kernel_timing = value != 0; ctx->kev_used = 0; ctx->kev_frame_start.clear();
+    } else return fail(ctx, RTGL_ERR_INVALID, std::string("unknown option ") + key);
     return RTGL_OK;
 }
 

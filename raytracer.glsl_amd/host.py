@@ -28,6 +28,7 @@ ABI_SYMBOLS = [
     "rtgl_clear_image", "rtgl_local_rows", "rtgl_local_row_to_global", "rtgl_device_image",
     "rtgl_bind_device_image", "rtgl_set_stream", "rtgl_get_counters", "rtgl_read_rng_state",
     "rtgl_set_option", "rtgl_get_option", "rtgl_last_frame_ms", "rtgl_last_frame_timing",
+    "rtgl_accumulated_timing", "rtgl_timing_reset",
 ]
 
 
@@ -100,6 +101,8 @@ def load_library() -> C.CDLL:
     L.rtgl_get_option.argtypes = [vp, C.c_char_p, C.POINTER(i)]
     L.rtgl_last_frame_ms.argtypes = [vp, C.POINTER(C.c_float)]
     L.rtgl_last_frame_timing.argtypes = [vp, C.POINTER(CFrameTiming)]
+    L.rtgl_accumulated_timing.argtypes = [vp, C.POINTER(CFrameTiming), C.POINTER(C.c_uint32)]
+    L.rtgl_timing_reset.argtypes = [vp]
     _lib = L
     return L
 
@@ -200,6 +203,14 @@ class Context:
         t = CFrameTiming()
         self._chk(self.lib.rtgl_last_frame_timing(self.h, C.byref(t)))
         return dict(frame_ms=float(t.frame_ms), intersect_ms=float(t.intersect_ms), intersect_launches=int(t.intersect_launches))
+
+    def accumulated_timing(self) -> dict:
+        t, n = CFrameTiming(), C.c_uint32()
+        self._chk(self.lib.rtgl_accumulated_timing(self.h, C.byref(t), C.byref(n)))
+        return dict(frames=int(n.value), frame_ms=float(t.frame_ms), intersect_ms=float(t.intersect_ms), intersect_launches=int(t.intersect_launches))
+
+    def timing_reset(self):
+        self._chk(self.lib.rtgl_timing_reset(self.h))
 
     # --- image
     def read_image(self) -> np.ndarray:
