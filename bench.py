@@ -75,6 +75,7 @@ def main():
     ap.add_argument("--wf-mode", type=int, default=None, help="triangle operand path: 0 scalar loads, 1 LDS tiles")
     ap.add_argument("--wf-chunk", type=int, default=None, help="triangles per work item of the split intersect kernel")
     ap.add_argument("--wf-early", type=int, default=None, help="leading bounces with the wave-level edge short circuit")
+    ap.add_argument("--wf-packed", type=int, default=None, help="v_pk_fma_f32 ray pairs (1) or plain v_fma_f32 (0)")
     ap.add_argument("--strip-rows", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sync-each-frame", action="store_true", help="diagnostic: host waits for every frame")
@@ -108,7 +109,7 @@ def main():
 
     ctx = rt.host.Context(W, H, device=local_rank, rank=rank, world=world, strip_rows=args.strip_rows)
     ctx.upload_scene(scene)
-    for key, val in (("kernel", args.kernel), ("wf_rays", args.wf_rays), ("wf_mode", args.wf_mode), ("wf_chunk", args.wf_chunk), ("wf_early", args.wf_early)):
+    for key, val in (("kernel", args.kernel), ("wf_rays", args.wf_rays), ("wf_mode", args.wf_mode), ("wf_chunk", args.wf_chunk), ("wf_early", args.wf_early), ("wf_packed", args.wf_packed)):
         if val is not None:
             ctx.set_option(key, val)
     gat = rt.tiling.FrameGatherer(W, H, rank, world, dev, args.strip_rows)
@@ -192,7 +193,7 @@ def main():
                                    f"{scene.spheres.shape[0]} spheres, cube map {scene.env.shape[1] if scene.env is not None else 0}^2, "
                                    f"1 spp/frame progressive, dof={base.use_dof}",
                        "parallelism": f"{world} GPU(s), {args.strip_rows}-row strips interleaved, gather to rank 0 every frame",
-                       "kernel": ctx.get_option("kernel"), "wf_rays": ctx.get_option("wf_rays"), "wf_mode": ctx.get_option("wf_mode"), "wf_chunk": ctx.get_option("wf_chunk"), "wf_early": ctx.get_option("wf_early")},
+                       "kernel": ctx.get_option("kernel"), "wf_rays": ctx.get_option("wf_rays"), "wf_mode": ctx.get_option("wf_mode"), "wf_chunk": ctx.get_option("wf_chunk"), "wf_early": ctx.get_option("wf_early"), "wf_packed": ctx.get_option("wf_packed")},
             "roofline": {"bound": "hbm", "achieved": bytes_per_launch / avg_launch_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": bytes_per_launch / avg_launch_s / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": kname, "launches_per_frame": launches_per_frame, "avg_launch_ms": avg_launch_s * 1e3,

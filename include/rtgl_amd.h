@@ -129,7 +129,7 @@ int rtgl_get_counters(rtgl_context *ctx, rtgl_counters *out);  /* synchronises *
 int rtgl_read_rng_state(rtgl_context *ctx, uint32_t *xyzw);    /* per local pixel final PCG4D state of the last frame; needs option "rng_state"=1 */
 /* keys: "kernel" (enum above), "wf_rays" (rays per lane 1/2/4/8), "wf_mode" (0 scalar-fed, 1 LDS tiles),
  * "wf_chunk" (triangles per work item of the split intersect kernel, multiple of 64), "wf_early" (leading bounces
- * that use the wave-level edge short circuit), "rng_state", "counters",
+ * that use the wave-level edge short circuit), "wf_packed" (v_pk_fma_f32 ray pairs on/off), "rng_state", "counters",
  * "kernel_timing" */
 int rtgl_set_option(rtgl_context *ctx, const char *key, int value);
 int rtgl_get_option(rtgl_context *ctx, const char *key, int *value);

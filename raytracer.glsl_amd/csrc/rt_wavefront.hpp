@@ -401,10 +401,10 @@ __device__ __forceinline__ float edge_chain(float ex, float ey, float ez, float 
 // :243-245): if no ray of the wave can pass edge 0 the other two edges are not evaluated, likewise after
 // edge 1.  Pays off when the rays of a wave are coherent (camera rays: bounce 0), costs a few percent when
 // they are not, so the host enables it per bounce.
-template <int R, bool EARLY>
+template <int R, bool EARLY, bool PACKED>
 __device__ __forceinline__ void scan_triangle(const TriCoef &T, const ScanRays<R> &sr, uint32_t off, uint16_t *cand, uint32_t &n_cand)
 {
-    if (!EARLY && (R % 2) == 0) {
+    if (!EARLY && PACKED && (R % 2) == 0) {
 #pragma unroll
         for (int q = 0; q < R / 2; ++q) {
             RayPair p;
@@ -466,7 +466,7 @@ __device__ __forceinline__ void exact_and_merge(const SceneView &sc, const RayQu
     if (kEps < t && t < kInf) atomicMin(&best[slot], ((unsigned long long)__float_as_uint(t) << 32) | v);
 }
 
-template <int R, int MODE, bool EARLY, bool kCount>
+template <int R, int MODE, bool EARLY, bool PACKED, bool kCount>
 __global__ void __launch_bounds__(256) intersect_kernel(SceneView sc, WaveBuffers wb, uint32_t bounce, uint32_t chunk_tris, Counters *counters)
 {
     __shared__ float4 lds_tile[MODE == kLds ? kTile * 5 : 1];
@@ -507,7 +507,7 @@ __global__ void __launch_bounds__(256) intersect_kernel(SceneView sc, WaveBuffer
             const uint32_t v1 = min(v0 + (uint32_t)kBoundGroup, v_end);
 #pragma unroll 2
             for (uint32_t v = v0; v < v1; ++v)
-                scan_triangle<R, EARLY>(load_coef(src + (size_t)v * 5), sr, v - v_begin, cand, n_cand);
+                scan_triangle<R, EARLY, PACKED>(load_coef(src + (size_t)v * 5), sr, v - v_begin, cand, n_cand);
         }
     } else {
         // tiles of kTile records: HBM -> LDS with coalesced 16-byte loads (thread i moves float4 i, i+256, ...),
@@ -534,7 +534,7 @@ __global__ void __launch_bounds__(256) intersect_kernel(SceneView sc, WaveBuffer
 #pragma unroll 2
                 for (uint32_t j = j0; j < j1; ++j) {
                     TriCoef nxt_coef = load_coef(lds_tile + min(j + 1u, (uint32_t)kTile - 1u) * 5);
-                    scan_triangle<R, EARLY>(cur, sr, vbase - v_begin + j, cand, n_cand);
+                    scan_triangle<R, EARLY, PACKED>(cur, sr, vbase - v_begin + j, cand, n_cand);
                     cur = nxt_coef;
                 }
             }

@@ -187,7 +187,7 @@ struct rtgl_context {
     bool tris_dirty = false, visits_dirty = false;
     FrameParams params{};
     bool have_params = false;
-    int opt_kernel = RTGL_KERNEL_WAVEFRONT_SPLIT, opt_rng_state = 0, opt_counters = 0, opt_kernel_timing = 0, opt_wf_rays = 4, opt_wf_mode = kLds, opt_wf_chunk = 512, opt_wf_early = 0;
+    int opt_kernel = RTGL_KERNEL_WAVEFRONT_SPLIT, opt_rng_state = 0, opt_counters = 0, opt_kernel_timing = 0, opt_wf_rays = 4, opt_wf_mode = kLds, opt_wf_chunk = 256, opt_wf_early = 0, opt_wf_packed = 0;
 };
 
 static int fail(rtgl_context *ctx, int code, const std::string &msg)
@@ -484,9 +484,10 @@ static void launch_intersect(rtgl_context *ctx, const SceneView &sc, uint32_t n0
     const uint32_t est = estimate_rays(ctx, n0, bounce);
     dim3 grid((est + 256u * R - 1) / (256u * R), (sc.n_tri_visits + chunk - 1) / chunk);
     const bool early = bounce < (uint32_t)ctx->opt_wf_early;     // wave-level edge short circuit on the coherent bounces
-#define RTGL_LAUNCH_ISECT(E, C) hipLaunchKernelGGL((intersect_kernel<R, MODE, E, C>), grid, dim3(256), 0, ctx->stream, sc, ctx->wb, bounce, chunk, ctx->d_counters)
-    if (early) { if (ctx->opt_counters) RTGL_LAUNCH_ISECT(true, true); else RTGL_LAUNCH_ISECT(true, false); }
-    else { if (ctx->opt_counters) RTGL_LAUNCH_ISECT(false, true); else RTGL_LAUNCH_ISECT(false, false); }
+#define RTGL_LAUNCH_ISECT(E, P, C) hipLaunchKernelGGL((intersect_kernel<R, MODE, E, P, C>), grid, dim3(256), 0, ctx->stream, sc, ctx->wb, bounce, chunk, ctx->d_counters)
+    if (early) { if (ctx->opt_counters) RTGL_LAUNCH_ISECT(true, false, true); else RTGL_LAUNCH_ISECT(true, false, false); }
+    else if (ctx->opt_wf_packed) { if (ctx->opt_counters) RTGL_LAUNCH_ISECT(false, true, true); else RTGL_LAUNCH_ISECT(false, true, false); }
+    else { if (ctx->opt_counters) RTGL_LAUNCH_ISECT(false, false, true); else RTGL_LAUNCH_ISECT(false, false, false); }
 #undef RTGL_LAUNCH_ISECT
 }
 
@@ -786,6 +787,8 @@ extern "C" int rtgl_set_option(rtgl_context *ctx, const char *key, int value)
     } else if (!strcmp(key, "wf_chunk")) {
         if (value < kBoundGroup || value % kBoundGroup || (uint32_t)value > kMaxChunk) return fail(ctx, RTGL_ERR_INVALID, "wf_chunk must be a multiple of 64 in [64, 4096]");
         ctx->opt_wf_chunk = value;
+    } else if (!strcmp(key, "wf_packed")) {
+        ctx->opt_wf_packed = value != 0;
     } else if (!strcmp(key, "wf_early")) {
         if (value < 0) return fail(ctx, RTGL_ERR_INVALID, "wf_early is the number of leading bounces with the wave-level edge short circuit (>= 0)");
         ctx->opt_wf_early = value;
@@ -810,6 +813,7 @@ extern "C" int rtgl_get_option(rtgl_context *ctx, const char *key, int *value)
     else if (!strcmp(key, "wf_mode")) *value = ctx->opt_wf_mode;
     else if (!strcmp(key, "wf_chunk")) *value = ctx->opt_wf_chunk;
     else if (!strcmp(key, "wf_early")) *value = ctx->opt_wf_early;
+    else if (!strcmp(key, "wf_packed")) *value = ctx->opt_wf_packed;
     else if (!strcmp(key, "rng_state")) *value = ctx->opt_rng_state;
     else if (!strcmp(key, "counters")) *value = ctx->opt_counters;
     else if (!strcmp(key, "kernel_timing")) *value = ctx->opt_kernel_timing;

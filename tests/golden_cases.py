@@ -69,6 +69,10 @@ def build_cases(sc):
     add("mesh_two_meshes_overlap", lambda: scene_two_meshes(sc), 96, 64, frame_sequence(sc, P2.replace(use_dof=0), 2))
     add("mesh_7k_bounce8", lambda: sc.scene_mesh(70, 50, env_size=64), 96, 64, frame_sequence(sc, P2, 1))
     add("mesh_stacked_duplicates", lambda: scene_stacked(sc), 64, 64, frame_sequence(sc, P2.replace(use_dof=0, max_bounce=4), 2))
+    add("mesh_degenerate_inputs", lambda: scene_degenerate(sc), 64, 64, frame_sequence(sc, P2.replace(use_dof=0, max_bounce=4), 2))
+    add("zero_bounces_three_samples", lambda: sc.scene_mesh(10, 5, env_size=16), 64, 64,
+        frame_sequence(sc, P2.replace(max_bounce=0, samples=3), 2), init="ramp")
+    add("mesh_three_samples", lambda: sc.scene_mesh(10, 5, env_size=16), 64, 64, frame_sequence(sc, P2.replace(samples=3, max_bounce=4), 2))
     add("mesh_odd_materials", lambda: scene_odd_materials(sc), 96, 64, frame_sequence(sc, P2.replace(use_dof=0), 2))
     # --- environment: tiny high-contrast cube (face edges, clamp), RGB (3-channel) cube, incomplete cube, background colour
     add("env_noise_cube", lambda: scene_env_only(sc, sc.noise_cubemap(4, 4)), 128, 128, frame_sequence(sc, P2.replace(max_bounce=2), 1))
@@ -155,6 +159,27 @@ def scene_stacked(sc):
     quad = np.array([[-8, -6, 2, 0], [-8, 4, 2, 0], [9, 4, 2, 0], [-8, -6, 2, 7], [9, 4, 2, 7], [9, -6, 2, 7]], np.float32)
     s.vertices = np.concatenate([s.vertices[:150], np.tile(quad, (30, 1)), s.vertices[150:]], axis=0)
     s.meshes = sc.make_meshes([(0, s.vertices.shape[0] // 3, 0)])
+    return s
+
+
+def scene_degenerate(sc):
+    """Zero-area triangles, a triangle with a NaN vertex, one with an infinite vertex, one astronomically
+    large, one microscopic, a zero-radius sphere and a NaN-radius sphere mixed into a normal scene."""
+    s = sc.scene_mesh(10, 5, env_size=16)
+    nan, inf = np.float32(np.nan), np.float32(np.inf)
+    bad = np.array([
+        [0, 0, 2, 0], [0, 0, 2, 0], [0, 0, 2, 0],                     # point triangle
+        [-3, 0, 2, 0], [0, 0, 2, 0], [3, 0, 2, 0],                     # collinear
+        [-3, 1, 2, 0], [nan, 2, 2, 0], [3, 1, 2, 0],                   # NaN vertex
+        [-3, -1, 2, 0], [0, inf, 2, 0], [3, -1, 2, 0],                 # infinite vertex
+        [-1e30, -1e30, 3, 2], [-1e30, 1e30, 3, 2], [1e30, 1e30, 3, 2],  # products overflow
+        [0, 0, 1, 3], [0, 1e-30, 1, 3], [1e-30, 1e-30, 1, 3],          # denormal-scale
+    ], np.float32)
+    s.vertices = np.concatenate([s.vertices[:60], bad, s.vertices[60:]], axis=0)
+    s.meshes = sc.make_meshes([(0, s.vertices.shape[0] // 3, 0)])
+    extra = sc.make_spheres([(2.0, 3.0, -5.0, 0.0, 2), (-4.0, 2.0, -8.0, float("nan"), 3), (5.0, -2.0, -6.0, 1.5, 2)])
+    s.spheres = np.concatenate([s.spheres, extra], axis=0)
+    s.nodes = sc.single_leaf(len(s.spheres))
     return s
 
 
