@@ -14,7 +14,7 @@ import numpy as np
 from .scenes import FrameParams, GlibcRand, Scene
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(PKG_DIR, "librtgl_amd.so")
+LIB_PATH = os.environ.get("RTGL_AMD_LIB") or os.path.join(PKG_DIR, "librtgl_amd.so")   # override: A/B of experimental builds
 CSRC_DIR = os.path.join(PKG_DIR, "csrc")
 
 KERNEL_MEGA, KERNEL_WAVEFRONT = 0, 1
