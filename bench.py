@@ -174,10 +174,14 @@ def main():
         share = 1.0 / world
         alg = algorithmic_bytes(W, H, cnt, scene)
         launches_per_frame = max(scan_launches // args.steps, 1)
-        avg_launch_s = max(scan_ms, 1e-9) / 1e3 / max(scan_launches, 1)     # (a scene without triangles has no scan launches)
+        avg_launch_s = max(scan_ms, 1e-9) / 1e3 / max(scan_launches, 1)
         bytes_per_launch = alg["scan"] * share / launches_per_frame
+        if scan_launches == 0:            # a scene without triangles has no scan launches: describe the whole frame instead
+            launches_per_frame, avg_launch_s, bytes_per_launch = 1, frame_ms / 1e3 / args.steps, alg["total"] * share
         flops_per_launch = cnt["triangle_tests"] * 36.0 * share / launches_per_frame   # 18 fma per edge-function triple
         kname = {0: "pathtrace_mega_kernel", 1: "bounce_kernel", 2: "intersect_kernel"}[ctx.get_option("kernel")]
+        if scan_launches == 0:
+            kname = "whole frame (generate_rays + shade)"
         traffic = None
         tf = os.path.join(ROOT, "profiles", "hbm_traffic.json")     # written by scripts/gpu_profile.sh (rocprofv3 PMC passes)
         if os.path.exists(tf):
