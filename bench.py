@@ -76,6 +76,8 @@ def main():
     ap.add_argument("--wf-chunk", type=int, default=None, help="triangles per work item of the split intersect kernel")
     ap.add_argument("--wf-early", type=int, default=None, help="leading bounces with the wave-level edge short circuit")
     ap.add_argument("--wf-packed", type=int, default=None, help="v_pk_fma_f32 ray pairs (1) or plain v_fma_f32 (0)")
+    ap.add_argument("--mf-sets", type=int, default=None, help="kernel 3: 32-ray sets per wave (2 or 4)")
+    ap.add_argument("--mf-chunk-groups", type=int, default=None, help="kernel 3: 40-triangle groups per work item")
     ap.add_argument("--strip-rows", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sync-each-frame", action="store_true", help="diagnostic: host waits for every frame")
@@ -109,7 +111,8 @@ def main():
 
     ctx = rt.host.Context(W, H, device=local_rank, rank=rank, world=world, strip_rows=args.strip_rows)
     ctx.upload_scene(scene)
-    for key, val in (("kernel", args.kernel), ("wf_rays", args.wf_rays), ("wf_mode", args.wf_mode), ("wf_chunk", args.wf_chunk), ("wf_early", args.wf_early), ("wf_packed", args.wf_packed)):
+    for key, val in (("kernel", args.kernel), ("wf_rays", args.wf_rays), ("wf_mode", args.wf_mode), ("wf_chunk", args.wf_chunk), ("wf_early", args.wf_early), ("wf_packed", args.wf_packed),
+                     ("mf_sets", args.mf_sets), ("mf_chunk_groups", args.mf_chunk_groups)):
         if val is not None:
             ctx.set_option(key, val)
     gat = rt.tiling.FrameGatherer(W, H, rank, world, dev, args.strip_rows)
@@ -179,7 +182,7 @@ def main():
         if scan_launches == 0:            # a scene without triangles has no scan launches: describe the whole frame instead
             launches_per_frame, avg_launch_s, bytes_per_launch = 1, frame_ms / 1e3 / args.steps, alg["total"] * share
         flops_per_launch = cnt["triangle_tests"] * 36.0 * share / launches_per_frame   # 18 fma per edge-function triple
-        kname = {0: "pathtrace_mega_kernel", 1: "bounce_kernel", 2: "intersect_kernel"}[ctx.get_option("kernel")]
+        kname = {0: "pathtrace_mega_kernel", 1: "bounce_kernel", 2: "intersect_kernel", 3: "intersect_mfma_kernel"}[ctx.get_option("kernel")]
         if scan_launches == 0:
             kname = "whole frame (generate_rays + shade)"
         traffic = None

@@ -71,7 +71,8 @@ typedef struct rtgl_counters {
 enum {
     RTGL_KERNEL_MEGA = 0,            /* one launch per frame, one lane per pixel, whole path in registers */
     RTGL_KERNEL_WAVEFRONT = 1,       /* one fused launch per bounce over the compacted ray queue */
-    RTGL_KERNEL_WAVEFRONT_SPLIT = 2  /* per bounce: intersect (ray blocks x triangle chunks) + shade; default */
+    RTGL_KERNEL_WAVEFRONT_SPLIT = 2, /* per bounce: intersect (ray blocks x triangle chunks) + shade; default */
+    RTGL_KERNEL_WAVEFRONT_MFMA = 3   /* as 2, with a conservative bf16 matrix-core broad phase in front of the exact test */
 };
 
 /* -- lifetime: replaces Renderer::Renderer(width,height) GL object creation (src/renderer.cpp:21-64).
@@ -129,7 +130,8 @@ int rtgl_get_counters(rtgl_context *ctx, rtgl_counters *out);  /* synchronises *
 int rtgl_read_rng_state(rtgl_context *ctx, uint32_t *xyzw);    /* per local pixel final PCG4D state of the last frame; needs option "rng_state"=1 */
 /* keys: "kernel" (enum above), "wf_rays" (rays per lane 1/2/4/8), "wf_mode" (0 scalar-fed, 1 LDS tiles),
  * "wf_chunk" (triangles per work item of the split intersect kernel, multiple of 64), "wf_early" (leading bounces
- * that use the wave-level edge short circuit), "wf_packed" (v_pk_fma_f32 ray pairs on/off), "rng_state", "counters",
+ * that use the wave-level edge short circuit), "wf_packed" (v_pk_fma_f32 ray pairs on/off), "mf_sets" (32-ray sets
+ * per wave of the kernel-3 scan: 2 or 4), "mf_chunk_groups" (40-triangle groups per work item), "rng_state", "counters",
  * "kernel_timing" */
 int rtgl_set_option(rtgl_context *ctx, const char *key, int value);
 int rtgl_get_option(rtgl_context *ctx, const char *key, int *value);

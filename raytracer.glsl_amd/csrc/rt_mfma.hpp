@@ -1,0 +1,256 @@
+// rt_mfma.hpp -- ray x triangle scan with a bf16 matrix-core broad phase (kernel variant 3).
+//
+// The three edge functions of the triangle test (:243-245) are a K = 6 contraction
+//     F[edge row][ray] = sum_k coef[edge row][k] * plucker[k][ray],   coef = (e_k, m_k), plucker = (d x o, d)
+// i.e. a (3 N_tri) x 6 by 6 x N_ray matrix product.  The fp32 VALU scan (rt_wavefront.hpp) spends 20 vector
+// instructions per test on it and is bound by the FP32 datapath (the exact-f32 MFMA shares that datapath,
+// tools/mfma_valu_rate.hip).  The bf16 matrix pipe does the same contraction 16x faster but only with 8-bit
+// mantissas -- far too coarse to DECIDE a hit, yet enough to REJECT almost everything conservatively:
+//
+//   * triangles are grouped 40 at a time (4 MFMA tiles of 10 triangles = 30 edge rows + 2 spare) around a
+//     local origin c, so Plucker magnitudes are those of the neighbourhood, not of the world origin;
+//   * per (ray, group) the lane computes cv' = d x (o - c) in fp32, packs (cv', d, 1, 0) to bf16 (B operand)
+//     and a threshold = -(bf16 error bound + fp32 bounds), see margin() below;
+//   * one v_mfma_f32_32x32x16_bf16 per (tile, 32 rays) yields the 30 edge values of 10 triangles for each ray
+//     (fp32 accumulate); a triangle survives unless min(F0,F1,F2) <= threshold;
+//   * survivors (a few per ray over the whole mesh) are parked in LDS and afterwards run through the exact
+//     reference-order test (tri_exact), whose hits merge by the same 64-bit atomicMin as the fp32 scan.
+//
+// Exactness: a triangle the reference accepts has exact edge values F_k > -(rounding of the reference's own
+// evaluation); the bf16 value differs from the exact one by at most margin_local (derivation at margin());
+// so it can never fall under the threshold.  What the broad phase lets through is irrelevant to the result:
+// every survivor gets the exact test.  NaN / inf anywhere make `mn <= threshold` false => survive.
+#pragma once
+#include "rt_wavefront.hpp"
+
+#pragma clang fp contract(off)
+
+namespace rt {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kMfTileTris = 10;                         // 2 lane-halves x 5 triangles x 3 edge rows (+1 spare row each)
+constexpr int kMfGroupTiles = 4;
+constexpr int kMfGroupTris = kMfTileTris * kMfGroupTiles;   // triangles sharing one local origin
+constexpr uint32_t kMfMaxChunkTiles = 512;              // parked entry: set (3 bits) << 12 | tile in chunk (9 bits) << 3 | u (3 bits)
+
+struct alignas(16) MfGroup {
+    float cx, cy, cz;   // local origin (centre of the group's bounding box)
+    float E;            // >= max |e_k|
+    float Ml;           // >= max |m'_k|                        (local moments)
+    float Mw;           // >= max |m_k|                         (world moments, as in TriEdges)
+    float P;            // >= max |v'_a| |v'_b|                 (bounds the fp32 rounding of the local cross products)
+    float pad1;
+};
+
+struct MfView {
+    const MfGroup *groups; uint32_t n_groups;
+    const uint4 *A;      // per tile: 32 rows x 8 bf16 (e.x e.y e.z m'.x m'.y m'.z bias 0), row-major
+};
+
+// row of the 32x32 accumulator tile held by lane-half h in register slot rho (ISA C/D layout)
+__host__ __device__ constexpr int mf_row(int rho, int h) { return (rho & 3) + 8 * (rho >> 2) + 4 * h; }
+
+// ---- upload time: local origins, bounds and the bf16 A matrices -------------------------------------------------
+__global__ void __launch_bounds__(64) prepare_mfma_kernel(const float4 *__restrict__ vertices, const uint32_t *__restrict__ visit_tri,
+                                                          uint32_t n_visits, uint32_t n_groups, MfGroup *__restrict__ groups, uint4 *__restrict__ A)
+{
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n_groups) return;
+    const uint32_t v_begin = g * kMfGroupTris, v_end = min(v_begin + (uint32_t)kMfGroupTris, n_visits);
+    f3 lo = mk(__builtin_inff(), __builtin_inff(), __builtin_inff()), hi = mk(-__builtin_inff(), -__builtin_inff(), -__builtin_inff());
+    bool bad = false;
+    for (uint32_t v = v_begin; v < v_end; ++v)
+        for (int k = 0; k < 3; ++k) {
+            float4 p = vertices[3 * (size_t)visit_tri[v] + k];
+            lo = mk(fminf(lo.x, p.x), fminf(lo.y, p.y), fminf(lo.z, p.z));
+            hi = mk(fmaxf(hi.x, p.x), fmaxf(hi.y, p.y), fmaxf(hi.z, p.z));
+            bad |= !(fabsf(p.x) < 1e18f) || !(fabsf(p.y) < 1e18f) || !(fabsf(p.z) < 1e18f);   // non-finite or so large that products overflow
+        }
+    const f3 c = mk(0.5f * lo.x + 0.5f * hi.x, 0.5f * lo.y + 0.5f * hi.y, 0.5f * lo.z + 0.5f * hi.z);
+    float E = 0.0f, Ml = 0.0f, Mw = 0.0f, P = 0.0f;
+    __bf16 *rows = reinterpret_cast<__bf16 *>(A + (size_t)g * kMfGroupTiles * 32);      // [tile][row][8]
+    for (int i = 0; i < kMfGroupTiles * 32 * 8; ++i) rows[i] = (__bf16)0.0f;
+    for (int t = 0; t < kMfGroupTiles; ++t)
+        for (int r = 0; r < 32; ++r) rows[(t * 32 + r) * 8 + 6] = (__bf16)(-3.0e38f);      // spare rows / missing triangles never survive
+    for (uint32_t v = v_begin; v < v_end; ++v) {
+        const uint32_t tri = visit_tri[v];
+        f3 w[3], wl[3];
+        for (int k = 0; k < 3; ++k) { float4 p = vertices[3 * (size_t)tri + k]; w[k] = mk(p.x, p.y, p.z); wl[k] = w[k] - c; }
+        const uint32_t in_group = v - v_begin, tile = in_group / kMfTileTris, tt = in_group % kMfTileTris;
+        const int h = (int)(tt / 5), u = (int)(tt % 5);
+        for (int k = 0; k < 3; ++k) {
+            const int a = (k + 1) % 3;                                   // edge k runs from vertex k to vertex a
+            const f3 e = w[a] - w[k];
+            const f3 ml = cross3(wl[a], wl[k]), mwv = cross3(w[a], w[k]);
+            E = fmaxf(E, __builtin_sqrtf(dot3(e, e)));
+            Ml = fmaxf(Ml, __builtin_sqrtf(dot3(ml, ml)));
+            P = fmaxf(P, __builtin_sqrtf(dot3(wl[a], wl[a])) * __builtin_sqrtf(dot3(wl[k], wl[k])));
+            Mw = fmaxf(Mw, __builtin_sqrtf(dot3(mwv, mwv)));
+            __bf16 *row = rows + ((size_t)tile * 32 + mf_row(3 * u + k, h)) * 8;
+            row[0] = (__bf16)e.x; row[1] = (__bf16)e.y; row[2] = (__bf16)e.z;
+            row[3] = (__bf16)ml.x; row[4] = (__bf16)ml.y; row[5] = (__bf16)ml.z;
+            row[6] = (__bf16)0.0f; row[7] = (__bf16)0.0f;
+        }
+    }
+    MfGroup G;
+    G.cx = c.x; G.cy = c.y; G.cz = c.z;
+    const float nanv = __builtin_nanf("");
+    G.E = bad ? nanv : E * 1.001f; G.Ml = bad ? nanv : Ml * 1.001f; G.Mw = bad ? nanv : Mw * 1.001f;   // NaN bounds: nothing is ever rejected
+    G.P = bad ? nanv : P * 1.001f; G.pad1 = 0.0f;
+    groups[g] = G;
+}
+
+// ---- per ray (constant over the scan) and per (ray, group) quantities ------------------------------------------
+struct MfRay {
+    f3 o, d;
+    float wd;        // >= |d|
+    float wod;       // >= |o| |d|
+    uint32_t dyz, one;   // bf16 pairs (d.y, d.z) and (1, 0)
+    bool valid;
+};
+
+__device__ __forceinline__ uint32_t pack_bf16(float lo, float hi)
+{
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    bf16x2 p; p[0] = (__bf16)lo; p[1] = (__bf16)hi;
+    return __builtin_bit_cast(uint32_t, p);
+}
+
+// margin(): how far the bf16 value F~ can lie above the exact F, plus how negative an edge value can be while the
+// reference still accepts the triangle.  With e~ = bf16(fl(e)), m~' = bf16(fl(v'_a x v'_b)), cv~' = bf16(fl(d x fl(o-c))),
+// d~ = bf16(d), bf16 unit round-off 2^-9, fp32 2^-24, P = |v'_a||v'_b| >= |m'|:
+//   |F~ - F| <= 2^-7.9 |e||cv'| + 2^-7.9 |m'||d| + 2^-21 (|e||o'| + P)|d|      (products exact, fp32 accumulate)
+// (first two terms: bf16 rounding of both factors; last: fp32 rounding of d x (o - c) and of v'_a x v'_b)
+// and the reference's own evaluation (3-term dots of fl(d x o), :226-245) accepts only if F > -2^-21 (|e||d||o| + |m||d|).
+// Everything is rounded up generously (>= 1.8x).
+__device__ __forceinline__ float mf_margin(const MfGroup &G, float ncv, float no, const MfRay &r)
+{
+    float local = 0.0078125f * __builtin_fmaf(G.E, ncv, G.Ml * r.wd);                         // 2^-7 (E|cv'| + Ml|d|)
+    float cancel = 9.5367431640625e-07f * (__builtin_fmaf(G.E, no, G.P) * r.wd);              // 2^-20 (E|o'| + P)|d|
+    float world = 9.5367431640625e-07f * __builtin_fmaf(G.E, r.wod, G.Mw * r.wd);             // 2^-20 (E|o||d| + Mw|d|)
+    return (local + cancel) + (world + 1e-30f);
+}
+
+template <int S, bool kCount>
+__global__ void __launch_bounds__(256) intersect_mfma_kernel(SceneView sc, WaveBuffers wb, MfView mf, uint32_t bounce,
+                                                             uint32_t chunk_groups, Counters *counters)
+{
+    constexpr uint32_t kSlots = 16;                           // parked survivors per lane; drained in place when nearly full
+    __shared__ uint16_t lds_cand[kSlots * 256];
+    const uint32_t n_rays = wb.counts[bounce];
+    const RayQueue qin = (bounce & 1u) ? wb.q[1] : wb.q[0];
+    unsigned long long *best = (bounce & 1u) ? wb.best[1] : wb.best[0];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, col = lane & 31, half = lane >> 5;
+    const uint32_t g_begin = blockIdx.y * chunk_groups, g_end = min(g_begin + chunk_groups, mf.n_groups);
+    const uint32_t tile_begin = g_begin * kMfGroupTiles;
+    const uint32_t v_chunk_begin = g_begin * kMfGroupTris, v_chunk_end = min(g_end * (uint32_t)kMfGroupTris, sc.n_tri_visits);
+    constexpr uint32_t kRaysPerBlock = 4u * S * 32u;
+    unsigned long long c_cand_total = 0;
+    uint16_t *cand = lds_cand + threadIdx.x;
+
+    for (uint32_t base = blockIdx.x * kRaysPerBlock; base < n_rays; base += gridDim.x * kRaysPerBlock) {
+        MfRay ray[S];
+        uint32_t slot_of[S];
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            const uint32_t slot = base + (uint32_t)(wave * S + s) * 32u + (uint32_t)col;   // both lane halves hold the same ray
+            slot_of[s] = slot;
+            MfRay &r = ray[s];
+            r.valid = slot < n_rays;
+            r.o = mk(0.0f, 0.0f, 0.0f); r.d = mk(0.0f, 0.0f, 0.0f);
+            if (r.valid) { float4 a = qin.a[slot], b = qin.b[slot]; r.o = mk(a.x, a.y, a.z); r.d = mk(a.w, b.x, b.y); }
+            r.wd = __builtin_sqrtf(dot3(r.d, r.d)) * 1.001f;
+            r.wod = (__builtin_sqrtf(dot3(r.o, r.o)) * 1.001f) * r.wd;
+            r.dyz = half ? 0u : pack_bf16(r.d.y, r.d.z);
+            r.one = half ? 0u : pack_bf16(1.0f, 0.0f);
+        }
+        uint32_t n_cand = 0, n_total = 0;
+        // exact reference-order test of the parked survivors of this lane
+        auto drain = [&]() {
+            for (uint32_t k = 0; k < n_cand; ++k) {
+                const uint32_t e = cand[k * 256u];
+                const uint32_t v = (tile_begin + ((e >> 3) & 511u)) * kMfTileTris + 5u * (uint32_t)half + (e & 7u);
+                const uint32_t s = e >> 12;
+                uint32_t slot = slot_of[0];
+#pragma unroll
+                for (int q = 1; q < S; ++q) slot = (s == (uint32_t)q) ? slot_of[q] : slot;
+                if (v < v_chunk_end) exact_and_merge(sc, qin, best, slot, v);
+            }
+            n_total += n_cand;
+            n_cand = 0;
+        };
+        // A tiles of the next group are fetched while the current group is processed (the loads would otherwise
+        // sit right in front of the MFMA that needs them: one exposed L2 round trip per tile)
+        uint4 a_cur[kMfGroupTiles], a_nxt[kMfGroupTiles];
+        auto fetch_group = [&](uint32_t g, uint4 (&dst)[kMfGroupTiles]) {
+#pragma unroll
+            for (int t = 0; t < kMfGroupTiles; ++t) {
+                dst[t] = make_uint4(0u, 0u, 0u, 0u);
+                if (!half && g < g_end) dst[t] = mf.A[((size_t)g * kMfGroupTiles + t) * 32 + col];   // whole groups are allocated
+            }
+        };
+        fetch_group(g_begin, a_cur);
+        for (uint32_t g = g_begin; g < g_end; ++g) {
+            fetch_group(g + 1u, a_nxt);
+            const MfGroup G = mf.groups[g];                                   // wave-uniform: scalar loads
+            bf16x8 B[S];
+            float thresh[S];
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                const MfRay &r = ray[s];
+                const f3 ol = r.o - mk(G.cx, G.cy, G.cz);
+                const f3 cvl = cross3(r.d, ol);
+                // v_sqrt_f32 (1 ulp) instead of the correctly rounded sequence: these are bounds, inflated by 1.001
+                const float ncv = __builtin_amdgcn_sqrtf(dot3(cvl, cvl)) * 1.001f, no = __builtin_amdgcn_sqrtf(dot3(ol, ol)) * 1.001f;
+                thresh[s] = r.valid ? -mf_margin(G, ncv, no, r) : __builtin_inff();          // empty slot: nothing survives
+                uint4 bw;
+                bw.x = half ? 0u : pack_bf16(cvl.x, cvl.y);
+                bw.y = half ? 0u : pack_bf16(cvl.z, r.d.x);
+                bw.z = r.dyz; bw.w = r.one;                                                   // k = 8..15 (upper lane half) is zero
+                B[s] = __builtin_bit_cast(bf16x8, bw);
+            }
+#pragma unroll
+            for (int t = 0; t < kMfGroupTiles; ++t) {
+                const uint32_t tile = g * kMfGroupTiles + t;
+                if (tile * kMfTileTris >= sc.n_tri_visits) break;                           // wave-uniform
+                const bf16x8 Aop = __builtin_bit_cast(bf16x8, a_cur[t]);
+#pragma unroll
+                for (int s = 0; s < S; ++s) {
+                    f32x16 acc = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Aop, B[s], acc, 0, 0, 0);
+                    // five tests per lane: v_min3 + v_cmp each, the survivor masks stay in SGPRs and ONE scalar branch
+                    // skips the parking code (taken by ~1 step in 8)
+                    unsigned long long surv[5], any = 0;
+#pragma unroll
+                    for (int u = 0; u < 5; ++u) {
+                        const float mn = __builtin_fminf(__builtin_fminf(acc[3 * u], acc[3 * u + 1]), acc[3 * u + 2]);
+                        surv[u] = __builtin_amdgcn_ballot_w64(!(mn <= thresh[s]));
+                        any |= surv[u];
+                    }
+                    if (any) {
+                        if (n_cand > kSlots - 5u) drain();                                  // room for the 5 triangles of this lane half
+#pragma unroll
+                        for (int u = 0; u < 5; ++u)
+                            if ((surv[u] >> lane) & 1ull) {                                 // survivor: exact test later
+                                cand[n_cand * 256u] = (uint16_t)((s << 12) | ((tile - tile_begin) << 3) | u);
+                                n_cand++;
+                            }
+                    }
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < kMfGroupTiles; ++t) a_cur[t] = a_nxt[t];
+        }
+        drain();
+        n_cand = n_total;
+        c_cand_total += n_cand;
+    }
+    if (kCount) {
+        atomicAdd(&counters->candidates, c_cand_total);
+        if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&counters->tri_tests, (unsigned long long)n_rays * (v_chunk_end - v_chunk_begin));
+    }
+}
+
+}  // namespace rt

@@ -11,6 +11,7 @@
 #include "../../include/rtgl_amd.h"
 #include "rt_device.hpp"
 #include "rt_wavefront.hpp"
+#include "rt_mfma.hpp"
 
 #pragma clang fp contract(off)
 
@@ -176,6 +177,7 @@ struct rtgl_context {
 
     // bounce-wavefront pipeline buffers
     float2 *d_group_bounds = nullptr;
+    MfGroup *d_mf_groups = nullptr; uint4 *d_mf_A = nullptr; uint32_t n_mf_groups = 0;   // bf16 matrix-core broad phase
     void *d_wave = nullptr; size_t wave_capacity = 0; bool wave_multi = false;   // queues (+ per-pixel state when u_samples > 1)
     uint32_t *d_counts = nullptr; uint32_t counts_capacity = 0;
     uint32_t *h_counts = nullptr;            // pinned: ray counts per bounce of the most recent finished frame
@@ -187,7 +189,7 @@ struct rtgl_context {
     bool tris_dirty = false, visits_dirty = false;
     FrameParams params{};
     bool have_params = false;
-    int opt_kernel = RTGL_KERNEL_WAVEFRONT_SPLIT, opt_rng_state = 0, opt_counters = 0, opt_kernel_timing = 0, opt_wf_rays = 4, opt_wf_mode = kLds, opt_wf_chunk = 256, opt_wf_early = 0, opt_wf_packed = 0;
+    int opt_kernel = RTGL_KERNEL_WAVEFRONT_SPLIT, opt_rng_state = 0, opt_counters = 0, opt_kernel_timing = 0, opt_wf_rays = 4, opt_wf_mode = kLds, opt_wf_chunk = 256, opt_wf_early = 0, opt_wf_packed = 0, opt_mf_sets = 4, opt_mf_chunk_groups = 64;
 };
 
 static int fail(rtgl_context *ctx, int code, const std::string &msg)
@@ -261,7 +263,7 @@ extern "C" void rtgl_destroy(rtgl_context *ctx)
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     void *ptrs[] = { ctx->d_spheres, ctx->d_materials, ctx->d_vertices, ctx->d_sphere_visits, ctx->d_edges, ctx->d_planes,
-                     ctx->d_env, ctx->d_image_own, ctx->d_rng, ctx->d_counters, ctx->d_u8, ctx->d_group_bounds, ctx->d_wave, ctx->d_counts };
+                     ctx->d_env, ctx->d_image_own, ctx->d_rng, ctx->d_counters, ctx->d_u8, ctx->d_group_bounds, ctx->d_wave, ctx->d_counts, ctx->d_mf_groups, ctx->d_mf_A };
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (hipEvent_t e : ctx->kev) (void)hipEventDestroy(e);
     if (ctx->h_counts) (void)hipHostFree(ctx->h_counts);
@@ -403,9 +405,18 @@ static int rebuild_triangles(rtgl_context *ctx)
         HIPCHK(ctx, hipMalloc((void **)&ctx->d_group_bounds, (size_t)n_groups * sizeof(float2)));
         hipLaunchKernelGGL(group_bounds_kernel, dim3(n_groups), dim3(64), 0, ctx->stream, ctx->d_edges, ctx->n_tri_visits, ctx->d_group_bounds);
         HIPCHK(ctx, hipGetLastError());
+        // bf16 broad-phase data: local origins, bounds, A matrices (rt_mfma.hpp)
+        if (ctx->d_mf_groups) { HIPCHK(ctx, hipFree(ctx->d_mf_groups)); ctx->d_mf_groups = nullptr; }
+        if (ctx->d_mf_A) { HIPCHK(ctx, hipFree(ctx->d_mf_A)); ctx->d_mf_A = nullptr; }
+        ctx->n_mf_groups = (ctx->n_tri_visits + kMfGroupTris - 1) / kMfGroupTris;
+        HIPCHK(ctx, hipMalloc((void **)&ctx->d_mf_groups, (size_t)ctx->n_mf_groups * sizeof(MfGroup)));
+        HIPCHK(ctx, hipMalloc((void **)&ctx->d_mf_A, (size_t)ctx->n_mf_groups * kMfGroupTiles * 32 * sizeof(uint4)));
+        hipLaunchKernelGGL(prepare_mfma_kernel, dim3((ctx->n_mf_groups + 63) / 64), dim3(64), 0, ctx->stream, ctx->d_vertices, d_visit,
+                           ctx->n_tri_visits, ctx->n_mf_groups, ctx->d_mf_groups, ctx->d_mf_A);
+        HIPCHK(ctx, hipGetLastError());
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
         HIPCHK(ctx, hipFree(d_visit));
-    }
+    } else ctx->n_mf_groups = 0;
     ctx->tris_dirty = false;
     return RTGL_OK;
 }
@@ -491,6 +502,19 @@ static void launch_intersect(rtgl_context *ctx, const SceneView &sc, uint32_t n0
 #undef RTGL_LAUNCH_ISECT
 }
 
+template <int S>
+static void launch_intersect_mfma(rtgl_context *ctx, const SceneView &sc, uint32_t n0, uint32_t bounce)
+{
+    const uint32_t chunk_groups = (uint32_t)ctx->opt_mf_chunk_groups;
+    const uint32_t est = estimate_rays(ctx, n0, bounce), rays_per_block = 4u * S * 32u;
+    dim3 grid((est + rays_per_block - 1) / rays_per_block, (ctx->n_mf_groups + chunk_groups - 1) / chunk_groups);
+    MfView mf{ctx->d_mf_groups, ctx->n_mf_groups, ctx->d_mf_A};
+    if (ctx->opt_counters)
+        hipLaunchKernelGGL((intersect_mfma_kernel<S, true>), grid, dim3(256), 0, ctx->stream, sc, ctx->wb, mf, bounce, chunk_groups, ctx->d_counters);
+    else
+        hipLaunchKernelGGL((intersect_mfma_kernel<S, false>), grid, dim3(256), 0, ctx->stream, sc, ctx->wb, mf, bounce, chunk_groups, ctx->d_counters);
+}
+
 static int launch_wavefront(rtgl_context *ctx, const SceneView &sc, const FrameParams &P, const ImageView &im, uint32_t n0, uint4 *rng_out)
 {
     const dim3 gen_grid((n0 + 255) / 256);
@@ -506,8 +530,12 @@ static int launch_wavefront(rtgl_context *ctx, const SceneView &sc, const FrameP
                            ctx->opt_counters ? ctx->d_counters : (Counters *)nullptr);
         for (uint32_t b = 0; b < P.max_bounce; ++b) {
             const int key = ctx->opt_wf_mode * 10 + ctx->opt_wf_rays;
-            if (ctx->opt_kernel == RTGL_KERNEL_WAVEFRONT_SPLIT) {
-                if (sc.n_tri_visits > 0) {
+            if (ctx->opt_kernel == RTGL_KERNEL_WAVEFRONT_SPLIT || ctx->opt_kernel == RTGL_KERNEL_WAVEFRONT_MFMA) {
+                if (sc.n_tri_visits > 0 && ctx->opt_kernel == RTGL_KERNEL_WAVEFRONT_MFMA) {
+                    kev_mark(ctx);
+                    if (ctx->opt_mf_sets == 2) launch_intersect_mfma<2>(ctx, sc, n0, b); else launch_intersect_mfma<4>(ctx, sc, n0, b);
+                    kev_mark(ctx);
+                } else if (sc.n_tri_visits > 0) {
                     kev_mark(ctx);
                     switch (key) {
                     case 1: launch_intersect<1, kScalar>(ctx, sc, n0, b); break;
@@ -778,7 +806,7 @@ extern "C" int rtgl_set_option(rtgl_context *ctx, const char *key, int value)
     ENTER(ctx);
     if (!key) return fail(ctx, RTGL_ERR_INVALID, "key is NULL");
     if (!strcmp(key, "kernel")) {
-        if (value != RTGL_KERNEL_MEGA && value != RTGL_KERNEL_WAVEFRONT && value != RTGL_KERNEL_WAVEFRONT_SPLIT)
+        if (value < RTGL_KERNEL_MEGA || value > RTGL_KERNEL_WAVEFRONT_MFMA)
             return fail(ctx, RTGL_ERR_INVALID, "unknown kernel variant");
         ctx->opt_kernel = value;
     } else if (!strcmp(key, "wf_rays")) {
@@ -787,6 +815,12 @@ extern "C" int rtgl_set_option(rtgl_context *ctx, const char *key, int value)
     } else if (!strcmp(key, "wf_chunk")) {
         if (value < kBoundGroup || value % kBoundGroup || (uint32_t)value > kMaxChunk) return fail(ctx, RTGL_ERR_INVALID, "wf_chunk must be a multiple of 64 in [64, 4096]");
         ctx->opt_wf_chunk = value;
+    } else if (!strcmp(key, "mf_sets")) {
+        if (value != 2 && value != 4) return fail(ctx, RTGL_ERR_INVALID, "mf_sets must be 2 or 4");
+        ctx->opt_mf_sets = value;
+    } else if (!strcmp(key, "mf_chunk_groups")) {
+        if (value < 1 || (uint32_t)value * kMfGroupTiles > kMfMaxChunkTiles) return fail(ctx, RTGL_ERR_INVALID, "mf_chunk_groups must be in [1, 128]");
+        ctx->opt_mf_chunk_groups = value;
     } else if (!strcmp(key, "wf_packed")) {
         ctx->opt_wf_packed = value != 0;
     } else if (!strcmp(key, "wf_early")) {
@@ -814,6 +848,8 @@ extern "C" int rtgl_get_option(rtgl_context *ctx, const char *key, int *value)
     else if (!strcmp(key, "wf_chunk")) *value = ctx->opt_wf_chunk;
     else if (!strcmp(key, "wf_early")) *value = ctx->opt_wf_early;
     else if (!strcmp(key, "wf_packed")) *value = ctx->opt_wf_packed;
+    else if (!strcmp(key, "mf_sets")) *value = ctx->opt_mf_sets;
+    else if (!strcmp(key, "mf_chunk_groups")) *value = ctx->opt_mf_chunk_groups;
     else if (!strcmp(key, "rng_state")) *value = ctx->opt_rng_state;
     else if (!strcmp(key, "counters")) *value = ctx->opt_counters;
     else if (!strcmp(key, "kernel_timing")) *value = ctx->opt_kernel_timing;

@@ -52,10 +52,13 @@ def test_c2_counters(c2_reference_image, rt):
     assert np.isfinite(img).all() and (img[..., 3] == 1.0).all()
 
 
-@pytest.mark.parametrize("variant", [(0, 0, 1, 1024), (1, 1, 2, 1024), (2, 0, 2, 512), (2, 1, 8, 256), (2, 1, 1, 2560)])
+@pytest.mark.parametrize("variant", [(0, 0, 1, 1024), (1, 1, 2, 1024), (2, 0, 2, 512), (2, 1, 8, 256), (2, 1, 1, 2560), (3, 0, 4, 64), (3, 0, 2, 16)])
 def test_c2_all_kernel_variants_identical(variant, c2_reference_image, rt):
     base = c2_reference_image[0]
-    opts = (("kernel", variant[0]), ("wf_mode", variant[1]), ("wf_rays", variant[2]), ("wf_chunk", variant[3]))
+    if variant[0] == 3:
+        opts = (("kernel", 3), ("mf_sets", variant[2]), ("mf_chunk_groups", variant[3]))
+    else:
+        opts = (("kernel", variant[0]), ("wf_mode", variant[1]), ("wf_rays", variant[2]), ("wf_chunk", variant[3]))
     img = render(rt, "C2", frames=2, options=opts)[0]
     assert (img.view(np.uint32) == base.view(np.uint32)).all()
 
@@ -88,6 +91,8 @@ def test_c4_100k_triangles_variants_agree_and_match_oracle_strip(rt, oracle):
     a, cnt, _, scene, plist = render(rt, "C4", frames=1, counters=True)
     b = render(rt, "C4", frames=1, options=(("kernel", 2), ("wf_mode", 0), ("wf_rays", 4)))[0]
     assert (a.view(np.uint32) == b.view(np.uint32)).all()
+    c = render(rt, "C4", frames=1, options=(("kernel", 3),))[0]
+    assert (a.view(np.uint32) == c.view(np.uint32)).all()
     assert cnt["triangle_tests"] == cnt["segments"] * 100000
     want = np.zeros_like(a)
     oracle.render(scene, plist[0], want, rect=(0, 536, 1920, 544), threads=16)
@@ -99,6 +104,8 @@ def test_c5_2160p_16_bounces_wide_dof(rt, oracle):
     assert cnt["paths"] == 3840 * 2160 and cnt["segments"] <= cnt["paths"] * 16
     b = render(rt, "C5", frames=1, options=(("kernel", 1), ("wf_mode", 1), ("wf_rays", 2)))[0]
     assert (a.view(np.uint32) == b.view(np.uint32)).all()
+    c = render(rt, "C5", frames=1, options=(("kernel", 3),))[0]
+    assert (a.view(np.uint32) == c.view(np.uint32)).all()
     want = np.zeros_like(a)
     oracle.render(scene, plist[0], want, rect=(0, 1080, 3840, 1084), threads=16)
     assert (a[1080:1084].view(np.uint32) == want[1080:1084].view(np.uint32)).all()

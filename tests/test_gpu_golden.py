@@ -33,6 +33,15 @@ def test_default_kernel_matches_reference_shader_output(path, rt):
     assert not neq.any(), f"{int(neq.sum())} of {neq.size} pixels differ from the reference shader's output"
 
 
+@pytest.mark.parametrize("path", CASE_FILES, ids=lambda p: os.path.basename(p)[:-4])
+def test_matrix_core_broad_phase_matches_reference_shader_output(path, rt):
+    """kernel 3: bf16 MFMA rejects, the exact reference-order test decides -- every golden case, bit for bit."""
+    meta, scene, frames, expected = load_case(path, rt)
+    img = render_case(rt, meta, scene, frames, options=(("kernel", 3), ("mf_chunk_groups", 2)))
+    neq = (img.view(np.uint32) != expected.view(np.uint32)).any(axis=2)
+    assert not neq.any(), f"{int(neq.sum())} of {neq.size} pixels differ from the reference shader's output"
+
+
 @pytest.mark.parametrize("kernel", [0, 1])
 @pytest.mark.parametrize("name", ["c1_reset_sequence", "c1_two_samples", "mesh_two_meshes_overlap", "mesh_odd_materials",
                                   "glass_inside_tir", "c1_ragged_70x53", "spheres_deep_chain", "env_noise_cube"])
