@@ -33,20 +33,23 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int kMfTileTris = 10;                         // 2 lane-halves x 5 triangles x 3 edge rows (+1 spare row each)
 constexpr int kMfGroupTiles = 4;
 constexpr int kMfGroupTris = kMfTileTris * kMfGroupTiles;   // triangles sharing one local origin
-constexpr uint32_t kMfMaxChunkTiles = 512;              // parked entry: set (3 bits) << 12 | tile in chunk (9 bits) << 3 | u (3 bits)
+constexpr uint32_t kMfMaxChunkTiles = 512;              // queued entry keeps the triangle offset inside the chunk in 16 bits
 
 struct alignas(16) MfGroup {
     float cx, cy, cz;   // local origin (centre of the group's bounding box)
     float E;            // >= max |e_k|
     float Ml;           // >= max |m'_k|                        (local moments)
-    float Mw;           // >= max |m_k|                         (world moments, as in TriEdges)
+    float Pw;           // >= max |v_a| |v_b| >= max |m_k|      (bounds the fp32 rounding of the reference's own cross(v_a, v_b))
     float P;            // >= max |v'_a| |v'_b|                 (bounds the fp32 rounding of the local cross products)
     float pad1;
 };
 
 struct MfView {
     const MfGroup *groups; uint32_t n_groups;
-    const uint4 *A;      // per tile: 32 rows x 8 bf16 (e.x e.y e.z m'.x m'.y m'.z bias 0), row-major
+    const uint4 *A;          // per tile: 32 rows x 8 bf16 (e.x e.y e.z m'.x m'.y m'.z bias 0), row-major
+    const uint32_t *order;   // storage position -> visit index.  Triangles are stored in Morton order of their centroids
+                             // so that the 40 of a group are neighbours (tight local bounds); hits are merged by VISIT
+                             // index, so the reference's first-visited-wins tie rule (:349) is unaffected by the reordering
 };
 
 // row of the 32x32 accumulator tile held by lane-half h in register slot rho (ISA C/D layout)
@@ -54,7 +57,8 @@ __host__ __device__ constexpr int mf_row(int rho, int h) { return (rho & 3) + 8 
 
 // ---- upload time: local origins, bounds and the bf16 A matrices -------------------------------------------------
 __global__ void __launch_bounds__(64) prepare_mfma_kernel(const float4 *__restrict__ vertices, const uint32_t *__restrict__ visit_tri,
-                                                          uint32_t n_visits, uint32_t n_groups, MfGroup *__restrict__ groups, uint4 *__restrict__ A)
+                                                          const uint32_t *__restrict__ order, uint32_t n_visits, uint32_t n_groups,
+                                                          MfGroup *__restrict__ groups, uint4 *__restrict__ A)
 {
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= n_groups) return;
@@ -63,19 +67,19 @@ __global__ void __launch_bounds__(64) prepare_mfma_kernel(const float4 *__restri
     bool bad = false;
     for (uint32_t v = v_begin; v < v_end; ++v)
         for (int k = 0; k < 3; ++k) {
-            float4 p = vertices[3 * (size_t)visit_tri[v] + k];
+            float4 p = vertices[3 * (size_t)visit_tri[order[v]] + k];
             lo = mk(fminf(lo.x, p.x), fminf(lo.y, p.y), fminf(lo.z, p.z));
             hi = mk(fmaxf(hi.x, p.x), fmaxf(hi.y, p.y), fmaxf(hi.z, p.z));
             bad |= !(fabsf(p.x) < 1e18f) || !(fabsf(p.y) < 1e18f) || !(fabsf(p.z) < 1e18f);   // non-finite or so large that products overflow
         }
     const f3 c = mk(0.5f * lo.x + 0.5f * hi.x, 0.5f * lo.y + 0.5f * hi.y, 0.5f * lo.z + 0.5f * hi.z);
-    float E = 0.0f, Ml = 0.0f, Mw = 0.0f, P = 0.0f;
+    float E = 0.0f, Ml = 0.0f, Pw = 0.0f, P = 0.0f;
     __bf16 *rows = reinterpret_cast<__bf16 *>(A + (size_t)g * kMfGroupTiles * 32);      // [tile][row][8]
     for (int i = 0; i < kMfGroupTiles * 32 * 8; ++i) rows[i] = (__bf16)0.0f;
     for (int t = 0; t < kMfGroupTiles; ++t)
         for (int r = 0; r < 32; ++r) rows[(t * 32 + r) * 8 + 6] = (__bf16)(-3.0e38f);      // spare rows / missing triangles never survive
     for (uint32_t v = v_begin; v < v_end; ++v) {
-        const uint32_t tri = visit_tri[v];
+        const uint32_t tri = visit_tri[order[v]];                       // v = storage position
         f3 w[3], wl[3];
         for (int k = 0; k < 3; ++k) { float4 p = vertices[3 * (size_t)tri + k]; w[k] = mk(p.x, p.y, p.z); wl[k] = w[k] - c; }
         const uint32_t in_group = v - v_begin, tile = in_group / kMfTileTris, tt = in_group % kMfTileTris;
@@ -83,11 +87,11 @@ __global__ void __launch_bounds__(64) prepare_mfma_kernel(const float4 *__restri
         for (int k = 0; k < 3; ++k) {
             const int a = (k + 1) % 3;                                   // edge k runs from vertex k to vertex a
             const f3 e = w[a] - w[k];
-            const f3 ml = cross3(wl[a], wl[k]), mwv = cross3(w[a], w[k]);
+            const f3 ml = cross3(wl[a], wl[k]);
             E = fmaxf(E, __builtin_sqrtf(dot3(e, e)));
             Ml = fmaxf(Ml, __builtin_sqrtf(dot3(ml, ml)));
             P = fmaxf(P, __builtin_sqrtf(dot3(wl[a], wl[a])) * __builtin_sqrtf(dot3(wl[k], wl[k])));
-            Mw = fmaxf(Mw, __builtin_sqrtf(dot3(mwv, mwv)));
+            Pw = fmaxf(Pw, __builtin_sqrtf(dot3(w[a], w[a])) * __builtin_sqrtf(dot3(w[k], w[k])));
             __bf16 *row = rows + ((size_t)tile * 32 + mf_row(3 * u + k, h)) * 8;
             row[0] = (__bf16)e.x; row[1] = (__bf16)e.y; row[2] = (__bf16)e.z;
             row[3] = (__bf16)ml.x; row[4] = (__bf16)ml.y; row[5] = (__bf16)ml.z;
@@ -97,7 +101,7 @@ __global__ void __launch_bounds__(64) prepare_mfma_kernel(const float4 *__restri
     MfGroup G;
     G.cx = c.x; G.cy = c.y; G.cz = c.z;
     const float nanv = __builtin_nanf("");
-    G.E = bad ? nanv : E * 1.001f; G.Ml = bad ? nanv : Ml * 1.001f; G.Mw = bad ? nanv : Mw * 1.001f;   // NaN bounds: nothing is ever rejected
+    G.E = bad ? nanv : E * 1.001f; G.Ml = bad ? nanv : Ml * 1.001f; G.Pw = bad ? nanv : Pw * 1.001f;   // NaN bounds: nothing is ever rejected
     G.P = bad ? nanv : P * 1.001f; G.pad1 = 0.0f;
     groups[g] = G;
 }
@@ -118,27 +122,33 @@ __device__ __forceinline__ uint32_t pack_bf16(float lo, float hi)
     return __builtin_bit_cast(uint32_t, p);
 }
 
-// margin(): how far the bf16 value F~ can lie above the exact F, plus how negative an edge value can be while the
-// reference still accepts the triangle.  With e~ = bf16(fl(e)), m~' = bf16(fl(v'_a x v'_b)), cv~' = bf16(fl(d x fl(o-c))),
-// d~ = bf16(d), bf16 unit round-off 2^-9, fp32 2^-24, P = |v'_a||v'_b| >= |m'|:
-//   |F~ - F| <= 2^-7.9 |e||cv'| + 2^-7.9 |m'||d| + 2^-21 (|e||o'| + P)|d|      (products exact, fp32 accumulate)
-// (first two terms: bf16 rounding of both factors; last: fp32 rounding of d x (o - c) and of v'_a x v'_b)
-// and the reference's own evaluation (3-term dots of fl(d x o), :226-245) accepts only if F > -2^-21 (|e||d||o| + |m||d|).
-// Everything is rounded up generously (>= 1.8x).
+// margin(): F := e.(d x o) + m.d in exact arithmetic on the float inputs (identical for world and local origin).
+// (1) bf16 side.  With e~ = bf16(fl(e)), m~' = bf16(fl(v'_a x v'_b)), cv~' = bf16(fl(d x fl(o - c))), d~ = bf16(d), bf16
+//     unit round-off 2^-9, fp32 2^-24, P = |v'_a||v'_b| >= |m'|, products exact and accumulated in fp32:
+//         |F~ - F| <= 2^-7.9 (|e||cv'| + |m'||d|) + 2^-21 (|e||o'| + P)|d|
+//     (first term: bf16 rounding of both factors; second: fp32 rounding of d x (o - c) and of v'_a x v'_b).
+// (2) reference side.  The shader accepts edge k iff -A < B with A = dot(fl(e), fl(d x o)), B = dot(fl(v_a x v_b), d)
+//     evaluated in fp32 (:226-245).  |A + B - F| <= 4u|e||d x o| + 3u|e||d||o| + 3u|v_a||v_b||d| + 3u|m||d|, u = 2^-24,
+//     so an accepted edge has F > -(7u E|o||d| + 6u Pw|d|) with Pw >= |v_a||v_b| >= |m|.
+// A triangle the reference accepts therefore has F~_k > -(local + cancel + world) for all three edges with the
+// generous constants below (2^-7 for 2^-7.9, 2^-20 = 16u for 7u / 6u / 2^-21).
 __device__ __forceinline__ float mf_margin(const MfGroup &G, float ncv, float no, const MfRay &r)
 {
     float local = 0.0078125f * __builtin_fmaf(G.E, ncv, G.Ml * r.wd);                         // 2^-7 (E|cv'| + Ml|d|)
     float cancel = 9.5367431640625e-07f * (__builtin_fmaf(G.E, no, G.P) * r.wd);              // 2^-20 (E|o'| + P)|d|
-    float world = 9.5367431640625e-07f * __builtin_fmaf(G.E, r.wod, G.Mw * r.wd);             // 2^-20 (E|o||d| + Mw|d|)
+    float world = 9.5367431640625e-07f * __builtin_fmaf(G.E, r.wod, G.Pw * r.wd);             // 2^-20 (E|o||d| + Pw|d|)
     return (local + cancel) + (world + 1e-30f);
 }
 
 template <int S, bool kCount>
 __global__ void __launch_bounds__(256) intersect_mfma_kernel(SceneView sc, WaveBuffers wb, MfView mf, uint32_t bounce,
-                                                             uint32_t chunk_groups, Counters *counters)
+                                                             uint32_t chunk_groups, Counters *counters, int debug_skip_exact)
 {
-    constexpr uint32_t kSlots = 16;                           // parked survivors per lane; drained in place when nearly full
-    __shared__ uint16_t lds_cand[kSlots * 256];
+    // Survivors of the broad phase go to a per-wave LDS queue (wave-aggregated push: ballot + prefix popcount),
+    // and the exact narrow phase pops 64 entries at a time, one per lane -- every lane busy -- instead of each lane
+    // working through its own short list while its neighbours idle.
+    constexpr uint32_t kQueue = 256;                          // entries per wave: (ray in wave) << 16 | triangle offset in chunk
+    __shared__ uint32_t lds_queue[4 * kQueue];
     const uint32_t n_rays = wb.counts[bounce];
     const RayQueue qin = (bounce & 1u) ? wb.q[1] : wb.q[0];
     unsigned long long *best = (bounce & 1u) ? wb.best[1] : wb.best[0];
@@ -148,15 +158,13 @@ __global__ void __launch_bounds__(256) intersect_mfma_kernel(SceneView sc, WaveB
     const uint32_t v_chunk_begin = g_begin * kMfGroupTris, v_chunk_end = min(g_end * (uint32_t)kMfGroupTris, sc.n_tri_visits);
     constexpr uint32_t kRaysPerBlock = 4u * S * 32u;
     unsigned long long c_cand_total = 0;
-    uint16_t *cand = lds_cand + threadIdx.x;
+    uint32_t *queue = lds_queue + wave * kQueue;
 
     for (uint32_t base = blockIdx.x * kRaysPerBlock; base < n_rays; base += gridDim.x * kRaysPerBlock) {
         MfRay ray[S];
-        uint32_t slot_of[S];
 #pragma unroll
         for (int s = 0; s < S; ++s) {
             const uint32_t slot = base + (uint32_t)(wave * S + s) * 32u + (uint32_t)col;   // both lane halves hold the same ray
-            slot_of[s] = slot;
             MfRay &r = ray[s];
             r.valid = slot < n_rays;
             r.o = mk(0.0f, 0.0f, 0.0f); r.d = mk(0.0f, 0.0f, 0.0f);
@@ -166,20 +174,19 @@ __global__ void __launch_bounds__(256) intersect_mfma_kernel(SceneView sc, WaveB
             r.dyz = half ? 0u : pack_bf16(r.d.y, r.d.z);
             r.one = half ? 0u : pack_bf16(1.0f, 0.0f);
         }
-        uint32_t n_cand = 0, n_total = 0;
-        // exact reference-order test of the parked survivors of this lane
-        auto drain = [&]() {
-            for (uint32_t k = 0; k < n_cand; ++k) {
-                const uint32_t e = cand[k * 256u];
-                const uint32_t v = (tile_begin + ((e >> 3) & 511u)) * kMfTileTris + 5u * (uint32_t)half + (e & 7u);
-                const uint32_t s = e >> 12;
-                uint32_t slot = slot_of[0];
-#pragma unroll
-                for (int q = 1; q < S; ++q) slot = (s == (uint32_t)q) ? slot_of[q] : slot;
-                if (v < v_chunk_end) exact_and_merge(sc, qin, best, slot, v);
+        uint32_t qn = 0, n_total = 0;                            // wave-uniform
+        const uint32_t wave_slot0 = base + (uint32_t)(wave * S) * 32u;
+        // Exact reference-order test of the queued survivors, 64 per pass with every lane busy.  (A separate narrow-phase
+        // kernel fed through a global candidate buffer was measured: 30 us per bounce on its own, but the extra launch
+        // and the buffer traffic made the frame 3% slower than doing it here.)
+        auto flush = [&]() {
+            for (uint32_t i = (uint32_t)lane; i < qn; i += 64u) {
+                const uint32_t e = queue[i];
+                const uint32_t pos = v_chunk_begin + (e & 0xffffu);               // storage position
+                if (pos < v_chunk_end && !debug_skip_exact) exact_and_merge(sc, qin, best, wave_slot0 + (e >> 16), mf.order[pos]);
             }
-            n_total += n_cand;
-            n_cand = 0;
+            n_total += qn;
+            qn = 0;
         };
         // A tiles of the next group are fetched while the current group is processed (the loads would otherwise
         // sit right in front of the MFMA that needs them: one exposed L2 round trip per tile)
@@ -230,21 +237,26 @@ __global__ void __launch_bounds__(256) intersect_mfma_kernel(SceneView sc, WaveB
                         any |= surv[u];
                     }
                     if (any) {
-                        if (n_cand > kSlots - 5u) drain();                                  // room for the 5 triangles of this lane half
 #pragma unroll
-                        for (int u = 0; u < 5; ++u)
-                            if ((surv[u] >> lane) & 1ull) {                                 // survivor: exact test later
-                                cand[n_cand * 256u] = (uint16_t)((s << 12) | ((tile - tile_begin) << 3) | u);
-                                n_cand++;
+                        for (int u = 0; u < 5; ++u) {
+                            const unsigned long long m = surv[u];
+                            if (m) {                                                        // wave-uniform
+                                if (qn > kQueue - 64u) flush();
+                                if ((m >> lane) & 1ull) {
+                                    const uint32_t v_off = (tile - tile_begin) * kMfTileTris + 5u * (uint32_t)half + (uint32_t)u;
+                                    queue[qn + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = ((uint32_t)(s * 32 + col) << 16) | v_off;
+                                }
+                                qn += (uint32_t)__popcll(m);
                             }
+                        }
                     }
                 }
             }
 #pragma unroll
             for (int t = 0; t < kMfGroupTiles; ++t) a_cur[t] = a_nxt[t];
         }
-        drain();
-        n_cand = n_total;
+        flush();
+        const uint32_t n_cand = (lane == 0) ? n_total : 0u;
         c_cand_total += n_cand;
     }
     if (kCount) {

@@ -160,7 +160,7 @@ struct rtgl_context {
     std::string error;
 
     // raw scene copies (host) used to rebuild derived buffers
-    std::vector<uint8_t> h_meshes, h_nodes;
+    std::vector<uint8_t> h_meshes, h_nodes, h_vertices;
     uint32_t n_meshes = 0, n_nodes = 0, n_vec4 = 0;
 
     // device buffers
@@ -177,7 +177,7 @@ struct rtgl_context {
 
     // bounce-wavefront pipeline buffers
     float2 *d_group_bounds = nullptr;
-    MfGroup *d_mf_groups = nullptr; uint4 *d_mf_A = nullptr; uint32_t n_mf_groups = 0;   // bf16 matrix-core broad phase
+    MfGroup *d_mf_groups = nullptr; uint4 *d_mf_A = nullptr; uint32_t *d_mf_order = nullptr; uint32_t n_mf_groups = 0;   // bf16 matrix-core broad phase
     void *d_wave = nullptr; size_t wave_capacity = 0; bool wave_multi = false;   // queues (+ per-pixel state when u_samples > 1)
     uint32_t *d_counts = nullptr; uint32_t counts_capacity = 0;
     uint32_t *h_counts = nullptr;            // pinned: ray counts per bounce of the most recent finished frame
@@ -189,7 +189,7 @@ struct rtgl_context {
     bool tris_dirty = false, visits_dirty = false;
     FrameParams params{};
     bool have_params = false;
-    int opt_kernel = RTGL_KERNEL_WAVEFRONT_SPLIT, opt_rng_state = 0, opt_counters = 0, opt_kernel_timing = 0, opt_wf_rays = 4, opt_wf_mode = kLds, opt_wf_chunk = 256, opt_wf_early = 0, opt_wf_packed = 0, opt_mf_sets = 4, opt_mf_chunk_groups = 64;
+    int opt_kernel = RTGL_KERNEL_WAVEFRONT_SPLIT, opt_rng_state = 0, opt_counters = 0, opt_kernel_timing = 0, opt_wf_rays = 4, opt_wf_mode = kLds, opt_wf_chunk = 256, opt_wf_early = 0, opt_wf_packed = 0, opt_mf_sets = 2, opt_mf_chunk_groups = 64, opt_debug_skip_exact = 0;
 };
 
 static int fail(rtgl_context *ctx, int code, const std::string &msg)
@@ -263,7 +263,7 @@ extern "C" void rtgl_destroy(rtgl_context *ctx)
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     void *ptrs[] = { ctx->d_spheres, ctx->d_materials, ctx->d_vertices, ctx->d_sphere_visits, ctx->d_edges, ctx->d_planes,
-                     ctx->d_env, ctx->d_image_own, ctx->d_rng, ctx->d_counters, ctx->d_u8, ctx->d_group_bounds, ctx->d_wave, ctx->d_counts, ctx->d_mf_groups, ctx->d_mf_A };
+                     ctx->d_env, ctx->d_image_own, ctx->d_rng, ctx->d_counters, ctx->d_u8, ctx->d_group_bounds, ctx->d_wave, ctx->d_counts, ctx->d_mf_groups, ctx->d_mf_A, ctx->d_mf_order };
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (hipEvent_t e : ctx->kev) (void)hipEventDestroy(e);
     if (ctx->h_counts) (void)hipHostFree(ctx->h_counts);
@@ -315,6 +315,7 @@ extern "C" int rtgl_upload_vertices(rtgl_context *ctx, const void *data, uint32_
     if (vec4_count && !data) return fail(ctx, RTGL_ERR_INVALID, "vertices is NULL");
     int rc = realloc_upload(ctx, ctx->d_vertices, data, (size_t)vec4_count * 16);
     if (rc) return rc;
+    ctx->h_vertices.assign((const uint8_t *)data, (const uint8_t *)data + (size_t)vec4_count * 16);   // host copy: spatial ordering of the triangles
     ctx->n_vec4 = vec4_count; ctx->tris_dirty = true;
     return RTGL_OK;
 }
@@ -377,6 +378,40 @@ static int rebuild_sphere_visits(rtgl_context *ctx)
     return RTGL_OK;
 }
 
+// Storage order of the triangle visits for the matrix-core broad phase: sorted by the Morton code of the triangle
+// centroid (10 bits per axis over the bounding box of all centroids), ties by visit index.  Only tightness of the
+// per-group bounds depends on it; non-finite centroids simply land in cell 0.
+static std::vector<uint32_t> morton_order(const rtgl_context *ctx, const std::vector<uint32_t> &visit_tri)
+{
+    const size_t n = visit_tri.size();
+    const float *vx = reinterpret_cast<const float *>(ctx->h_vertices.data());
+    std::vector<float> cen(3 * n);
+    float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+    for (size_t v = 0; v < n; ++v)
+        for (int a = 0; a < 3; ++a) {
+            const float *t = vx + (size_t)visit_tri[v] * 12;
+            float c = (t[a] + t[4 + a] + t[8 + a]) * (1.0f / 3.0f);
+            cen[3 * v + a] = c;
+            if (c == c && c > -1.0e30f && c < 1.0e30f) { lo[a] = std::min(lo[a], c); hi[a] = std::max(hi[a], c); }
+        }
+    auto spread = [](uint64_t x) { x &= 0x3ff; x = (x | (x << 16)) & 0x30000ff; x = (x | (x << 8)) & 0x300f00f; x = (x | (x << 4)) & 0x30c30c3; x = (x | (x << 2)) & 0x9249249; return x; };
+    std::vector<std::pair<uint64_t, uint32_t>> keyed(n);
+    for (size_t v = 0; v < n; ++v) {
+        uint64_t code = 0;
+        for (int a = 0; a < 3; ++a) {
+            const float c = cen[3 * v + a], ext = hi[a] - lo[a];
+            uint64_t q = 0;
+            if (c == c && ext > 0.0f && c >= lo[a] && c <= hi[a]) q = (uint64_t)std::min(1023.0f, (c - lo[a]) / ext * 1023.0f);
+            code |= spread(q) << a;
+        }
+        keyed[v] = {code, (uint32_t)v};
+    }
+    std::sort(keyed.begin(), keyed.end());
+    std::vector<uint32_t> order(n);
+    for (size_t i = 0; i < n; ++i) order[i] = keyed[i].second;
+    return order;
+}
+
 static int rebuild_triangles(rtgl_context *ctx)
 {
     std::vector<uint32_t> visit_tri;
@@ -408,11 +443,15 @@ static int rebuild_triangles(rtgl_context *ctx)
         // bf16 broad-phase data: local origins, bounds, A matrices (rt_mfma.hpp)
         if (ctx->d_mf_groups) { HIPCHK(ctx, hipFree(ctx->d_mf_groups)); ctx->d_mf_groups = nullptr; }
         if (ctx->d_mf_A) { HIPCHK(ctx, hipFree(ctx->d_mf_A)); ctx->d_mf_A = nullptr; }
+        if (ctx->d_mf_order) { HIPCHK(ctx, hipFree(ctx->d_mf_order)); ctx->d_mf_order = nullptr; }
         ctx->n_mf_groups = (ctx->n_tri_visits + kMfGroupTris - 1) / kMfGroupTris;
+        const std::vector<uint32_t> order = morton_order(ctx, visit_tri);
+        HIPCHK(ctx, hipMalloc((void **)&ctx->d_mf_order, order.size() * 4));
+        HIPCHK(ctx, hipMemcpyAsync(ctx->d_mf_order, order.data(), order.size() * 4, hipMemcpyHostToDevice, ctx->stream));
         HIPCHK(ctx, hipMalloc((void **)&ctx->d_mf_groups, (size_t)ctx->n_mf_groups * sizeof(MfGroup)));
         HIPCHK(ctx, hipMalloc((void **)&ctx->d_mf_A, (size_t)ctx->n_mf_groups * kMfGroupTiles * 32 * sizeof(uint4)));
         hipLaunchKernelGGL(prepare_mfma_kernel, dim3((ctx->n_mf_groups + 63) / 64), dim3(64), 0, ctx->stream, ctx->d_vertices, d_visit,
-                           ctx->n_tri_visits, ctx->n_mf_groups, ctx->d_mf_groups, ctx->d_mf_A);
+                           ctx->d_mf_order, ctx->n_tri_visits, ctx->n_mf_groups, ctx->d_mf_groups, ctx->d_mf_A);
         HIPCHK(ctx, hipGetLastError());
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
         HIPCHK(ctx, hipFree(d_visit));
@@ -508,11 +547,11 @@ static void launch_intersect_mfma(rtgl_context *ctx, const SceneView &sc, uint32
     const uint32_t chunk_groups = (uint32_t)ctx->opt_mf_chunk_groups;
     const uint32_t est = estimate_rays(ctx, n0, bounce), rays_per_block = 4u * S * 32u;
     dim3 grid((est + rays_per_block - 1) / rays_per_block, (ctx->n_mf_groups + chunk_groups - 1) / chunk_groups);
-    MfView mf{ctx->d_mf_groups, ctx->n_mf_groups, ctx->d_mf_A};
+    MfView mf{ctx->d_mf_groups, ctx->n_mf_groups, ctx->d_mf_A, ctx->d_mf_order};
     if (ctx->opt_counters)
-        hipLaunchKernelGGL((intersect_mfma_kernel<S, true>), grid, dim3(256), 0, ctx->stream, sc, ctx->wb, mf, bounce, chunk_groups, ctx->d_counters);
+        hipLaunchKernelGGL((intersect_mfma_kernel<S, true>), grid, dim3(256), 0, ctx->stream, sc, ctx->wb, mf, bounce, chunk_groups, ctx->d_counters, ctx->opt_debug_skip_exact);
     else
-        hipLaunchKernelGGL((intersect_mfma_kernel<S, false>), grid, dim3(256), 0, ctx->stream, sc, ctx->wb, mf, bounce, chunk_groups, ctx->d_counters);
+        hipLaunchKernelGGL((intersect_mfma_kernel<S, false>), grid, dim3(256), 0, ctx->stream, sc, ctx->wb, mf, bounce, chunk_groups, ctx->d_counters, ctx->opt_debug_skip_exact);
 }
 
 static int launch_wavefront(rtgl_context *ctx, const SceneView &sc, const FrameParams &P, const ImageView &im, uint32_t n0, uint4 *rng_out)
@@ -815,6 +854,8 @@ extern "C" int rtgl_set_option(rtgl_context *ctx, const char *key, int value)
     } else if (!strcmp(key, "wf_chunk")) {
         if (value < kBoundGroup || value % kBoundGroup || (uint32_t)value > kMaxChunk) return fail(ctx, RTGL_ERR_INVALID, "wf_chunk must be a multiple of 64 in [64, 4096]");
         ctx->opt_wf_chunk = value;
+    } else if (!strcmp(key, "debug_skip_exact")) {      // timing diagnostics only: the image is wrong
+        ctx->opt_debug_skip_exact = value != 0;
     } else if (!strcmp(key, "mf_sets")) {
         if (value != 2 && value != 4) return fail(ctx, RTGL_ERR_INVALID, "mf_sets must be 2 or 4");
         ctx->opt_mf_sets = value;
