@@ -78,7 +78,8 @@ def main():
     ap.add_argument("--wf-packed", type=int, default=None, help="v_pk_fma_f32 ray pairs (1) or plain v_fma_f32 (0)")
     ap.add_argument("--debug-skip-exact", type=int, default=None, help="diagnostic (wrong image): kernel 3 without the exact narrow phase")
     ap.add_argument("--mf-sets", type=int, default=None, help="kernel 3: 32-ray sets per wave (2 or 4)")
-    ap.add_argument("--mf-chunk-groups", type=int, default=None, help="kernel 3: 40-triangle groups per work item")
+    ap.add_argument("--mf-chunk-quads", type=int, default=None, help="kernel 3: 40-triangle quads per work item")
+    ap.add_argument("--mf-group-quads", type=int, default=None, help="kernel 3: quads sharing one local origin (1, 2, 4, 8, 16)")
     ap.add_argument("--strip-rows", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sync-each-frame", action="store_true", help="diagnostic: host waits for every frame")
@@ -113,7 +114,7 @@ def main():
     ctx = rt.host.Context(W, H, device=local_rank, rank=rank, world=world, strip_rows=args.strip_rows)
     ctx.upload_scene(scene)
     for key, val in (("kernel", args.kernel), ("wf_rays", args.wf_rays), ("wf_mode", args.wf_mode), ("wf_chunk", args.wf_chunk), ("wf_early", args.wf_early), ("wf_packed", args.wf_packed),
-                     ("mf_sets", args.mf_sets), ("mf_chunk_groups", args.mf_chunk_groups), ("debug_skip_exact", args.debug_skip_exact)):
+                     ("mf_sets", args.mf_sets), ("mf_chunk_quads", args.mf_chunk_quads), ("mf_group_quads", args.mf_group_quads), ("debug_skip_exact", args.debug_skip_exact)):
         if val is not None:
             ctx.set_option(key, val)
     gat = rt.tiling.FrameGatherer(W, H, rank, world, dev, args.strip_rows)

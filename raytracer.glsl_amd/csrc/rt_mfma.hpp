@@ -31,9 +31,10 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int kMfTileTris = 10;                         // 2 lane-halves x 5 triangles x 3 edge rows (+1 spare row each)
-constexpr int kMfGroupTiles = 4;
-constexpr int kMfGroupTris = kMfTileTris * kMfGroupTiles;   // triangles sharing one local origin
-constexpr uint32_t kMfMaxChunkTiles = 512;              // queued entry keeps the triangle offset inside the chunk in 16 bits
+constexpr int kMfQuadTiles = 4;                         // tiles fetched together (one "quad" = 40 triangles)
+constexpr int kMfQuadTris = kMfTileTris * kMfQuadTiles;
+constexpr uint32_t kMfMaxChunkQuads = 128;              // queued entry keeps the triangle offset inside the chunk in 16 bits
+constexpr uint32_t kMfMaxGroupQuads = 16;               // a group = 1, 2, 4, 8 or 16 quads sharing one local origin and one set of bounds
 
 struct alignas(16) MfGroup {
     float cx, cy, cz;   // local origin (centre of the group's bounding box)
@@ -46,9 +47,11 @@ struct alignas(16) MfGroup {
 
 struct MfView {
     const MfGroup *groups; uint32_t n_groups;
-    const uint4 *A;          // per tile: 32 rows x 8 bf16 (e.x e.y e.z m'.x m'.y m'.z bias 0), row-major
+    uint32_t group_quads;    // quads per group (power of two); storage is allocated in whole groups
+    uint32_t n_quads;        // = n_groups * group_quads
+    const uint4 *A;          // per tile: 32 rows x 8 bf16 (e.x e.y e.z m'.x m'.y m'.z bias 0), row-major; n_quads quads + one all-zero quad
     const uint32_t *order;   // storage position -> visit index.  Triangles are stored in Morton order of their centroids
-                             // so that the 40 of a group are neighbours (tight local bounds); hits are merged by VISIT
+                             // so that the triangles of a group are neighbours (tight local bounds); hits are merged by VISIT
                              // index, so the reference's first-visited-wins tie rule (:349) is unaffected by the reordering
 };
 
@@ -58,11 +61,12 @@ __host__ __device__ constexpr int mf_row(int rho, int h) { return (rho & 3) + 8 
 // ---- upload time: local origins, bounds and the bf16 A matrices -------------------------------------------------
 __global__ void __launch_bounds__(64) prepare_mfma_kernel(const float4 *__restrict__ vertices, const uint32_t *__restrict__ visit_tri,
                                                           const uint32_t *__restrict__ order, uint32_t n_visits, uint32_t n_groups,
-                                                          MfGroup *__restrict__ groups, uint4 *__restrict__ A)
+                                                          uint32_t group_quads, MfGroup *__restrict__ groups, uint4 *__restrict__ A)
 {
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= n_groups) return;
-    const uint32_t v_begin = g * kMfGroupTris, v_end = min(v_begin + (uint32_t)kMfGroupTris, n_visits);
+    const uint32_t group_tiles = group_quads * kMfQuadTiles, group_tris = group_tiles * kMfTileTris;
+    const uint32_t v_begin = g * group_tris, v_end = min(v_begin + group_tris, n_visits);
     f3 lo = mk(__builtin_inff(), __builtin_inff(), __builtin_inff()), hi = mk(-__builtin_inff(), -__builtin_inff(), -__builtin_inff());
     bool bad = false;
     for (uint32_t v = v_begin; v < v_end; ++v)
@@ -74,9 +78,9 @@ __global__ void __launch_bounds__(64) prepare_mfma_kernel(const float4 *__restri
         }
     const f3 c = mk(0.5f * lo.x + 0.5f * hi.x, 0.5f * lo.y + 0.5f * hi.y, 0.5f * lo.z + 0.5f * hi.z);
     float E = 0.0f, Ml = 0.0f, Pw = 0.0f, P = 0.0f;
-    __bf16 *rows = reinterpret_cast<__bf16 *>(A + (size_t)g * kMfGroupTiles * 32);      // [tile][row][8]
-    for (int i = 0; i < kMfGroupTiles * 32 * 8; ++i) rows[i] = (__bf16)0.0f;
-    for (int t = 0; t < kMfGroupTiles; ++t)
+    __bf16 *rows = reinterpret_cast<__bf16 *>(A + (size_t)g * group_tiles * 32);        // [tile][row][8]
+    for (uint32_t i = 0; i < group_tiles * 32 * 8; ++i) rows[i] = (__bf16)0.0f;
+    for (uint32_t t = 0; t < group_tiles; ++t)
         for (int r = 0; r < 32; ++r) rows[(t * 32 + r) * 8 + 6] = (__bf16)(-3.0e38f);      // spare rows / missing triangles never survive
     for (uint32_t v = v_begin; v < v_end; ++v) {
         const uint32_t tri = visit_tri[order[v]];                       // v = storage position
@@ -140,25 +144,67 @@ __device__ __forceinline__ float mf_margin(const MfGroup &G, float ncv, float no
     return (local + cancel) + (world + 1e-30f);
 }
 
+// Exact reference-order test of the queued survivors, 64 per pass with every lane busy.  Kept out of line: it is
+// reached from every unrolled (tile, ray set, triangle) position of the broad-phase loop and inlining it there put
+// ~40 copies of the exact test between the hot instructions.  (A separate narrow-phase kernel fed through a global
+// candidate buffer was also measured: 30 us per bounce on its own, but the extra launch and the buffer traffic made
+// the frame 3% slower than doing it here.)
+// Everything is passed BY VALUE: a reference to a kernel-argument struct would force the kernel to keep that struct in
+// scratch memory and read its fields back from there inside the hot loop (seen: a scratch load + s_waitcnt vmcnt(0) per
+// step, which also waited for the A-tile prefetch).
+struct MfFlushArgs {
+    const float4 *ray_a, *ray_b;
+    const TriEdges *tri_edges; const TriPlane *tri_planes;
+    unsigned long long *best;
+    const uint32_t *order;
+    uint32_t wave_slot0, v_chunk_begin, v_chunk_end;
+    int debug_skip_exact;
+};
+
+__device__ __attribute__((noinline)) void mf_flush(MfFlushArgs f, const uint32_t *queue, uint32_t qn)
+{
+    for (uint32_t i = threadIdx.x & 63u; i < qn; i += 64u) {
+        const uint32_t e = queue[i];
+        const uint32_t pos = f.v_chunk_begin + (e & 0xffffu);                 // storage position
+        if (pos < f.v_chunk_end && !f.debug_skip_exact) {
+            const uint32_t slot = f.wave_slot0 + (e >> 16), v = f.order[pos];
+            const float4 a = f.ray_a[slot], b = f.ray_b[slot];
+            TriRay tr; tr.o = mk(a.x, a.y, a.z); tr.d = mk(a.w, b.x, b.y); tr.cv = cross3(tr.d, tr.o); tr.ncv = tr.nd = 0.0f;
+            const float t = tri_exact(f.tri_edges[v], f.tri_planes[v], tr);
+            if (kEps < t && t < kInf) atomicMin(&f.best[slot], ((unsigned long long)__float_as_uint(t) << 32) | v);   // as exact_and_merge()
+        }
+    }
+}
+
 template <int S, bool kCount>
 __global__ void __launch_bounds__(256) intersect_mfma_kernel(SceneView sc, WaveBuffers wb, MfView mf, uint32_t bounce,
-                                                             uint32_t chunk_groups, Counters *counters, int debug_skip_exact)
+                                                             uint32_t chunk_quads, Counters *__restrict__ counters, int debug_skip_exact)
 {
-    // Survivors of the broad phase go to a per-wave LDS queue (wave-aggregated push: ballot + prefix popcount),
-    // and the exact narrow phase pops 64 entries at a time, one per lane -- every lane busy -- instead of each lane
-    // working through its own short list while its neighbours idle.
+    // grid: x = blocks of 4 waves x S ray sets x 32 rays (grid-stride), y = chunks of `chunk_quads` quads (a multiple of
+    // the group size, so a group never straddles two chunks)
     constexpr uint32_t kQueue = 256;                          // entries per wave: (ray in wave) << 16 | triangle offset in chunk
     __shared__ uint32_t lds_queue[4 * kQueue];
     const uint32_t n_rays = wb.counts[bounce];
     const RayQueue qin = (bounce & 1u) ? wb.q[1] : wb.q[0];
     unsigned long long *best = (bounce & 1u) ? wb.best[1] : wb.best[0];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, col = lane & 31, half = lane >> 5;
-    const uint32_t g_begin = blockIdx.y * chunk_groups, g_end = min(g_begin + chunk_groups, mf.n_groups);
-    const uint32_t tile_begin = g_begin * kMfGroupTiles;
-    const uint32_t v_chunk_begin = g_begin * kMfGroupTris, v_chunk_end = min(g_end * (uint32_t)kMfGroupTris, sc.n_tri_visits);
+    const uint32_t q_begin = blockIdx.y * chunk_quads, q_end = min(q_begin + chunk_quads, mf.n_quads);
+    const uint32_t tile_begin = q_begin * kMfQuadTiles;
+    const uint32_t v_chunk_begin = q_begin * kMfQuadTris, v_chunk_end = min(q_end * (uint32_t)kMfQuadTris, sc.n_tri_visits);
+    const uint32_t group_mask = mf.group_quads - 1u, group_shift = (uint32_t)__builtin_ctz(mf.group_quads);
     constexpr uint32_t kRaysPerBlock = 4u * S * 32u;
     unsigned long long c_cand_total = 0;
     uint32_t *queue = lds_queue + wave * kQueue;
+    const uint32_t n_tri_visits = sc.n_tri_visits;
+    MfFlushArgs fa{qin.a, qin.b, sc.tri_edges, sc.tri_planes, best, mf.order, 0u, v_chunk_begin, v_chunk_end, debug_skip_exact};
+    // group records through the constant address space: uniform index => s_load, which neither waits on nor is held up by
+    // the vector-memory counter the A-tile prefetch uses
+    typedef const float __attribute__((address_space(4))) *ConstFloats;
+    const ConstFloats groups_k = (ConstFloats)(uintptr_t)mf.groups;
+    // A tiles: every lane loads 16 bytes per tile from base + a_off + 512 t.  Lanes 0-31 (k = 0..7) walk the tiles, lanes
+    // 32-63 (k = 8..15, unused) keep reading the all-zero padding quad behind the last one: no exec masking, no re-zeroing
+    const char *A_bytes = reinterpret_cast<const char *>(mf.A);
+    const uint32_t a_inc = half ? 0u : (uint32_t)(kMfQuadTiles * 512);
 
     for (uint32_t base = blockIdx.x * kRaysPerBlock; base < n_rays; base += gridDim.x * kRaysPerBlock) {
         MfRay ray[S];
@@ -176,70 +222,78 @@ __global__ void __launch_bounds__(256) intersect_mfma_kernel(SceneView sc, WaveB
         }
         uint32_t qn = 0, n_total = 0;                            // wave-uniform
         const uint32_t wave_slot0 = base + (uint32_t)(wave * S) * 32u;
-        // Exact reference-order test of the queued survivors, 64 per pass with every lane busy.  (A separate narrow-phase
-        // kernel fed through a global candidate buffer was measured: 30 us per bounce on its own, but the extra launch
-        // and the buffer traffic made the frame 3% slower than doing it here.)
         auto flush = [&]() {
-            for (uint32_t i = (uint32_t)lane; i < qn; i += 64u) {
-                const uint32_t e = queue[i];
-                const uint32_t pos = v_chunk_begin + (e & 0xffffu);               // storage position
-                if (pos < v_chunk_end && !debug_skip_exact) exact_and_merge(sc, qin, best, wave_slot0 + (e >> 16), mf.order[pos]);
-            }
+            fa.wave_slot0 = wave_slot0;
+            mf_flush(fa, queue, qn);
             n_total += qn;
             qn = 0;
         };
-        // A tiles of the next group are fetched while the current group is processed (the loads would otherwise
-        // sit right in front of the MFMA that needs them: one exposed L2 round trip per tile)
-        uint4 a_cur[kMfGroupTiles], a_nxt[kMfGroupTiles];
-        auto fetch_group = [&](uint32_t g, uint4 (&dst)[kMfGroupTiles]) {
+        // The A tiles of the next quad are fetched while the current one is processed (the loads would otherwise sit
+        // right in front of the MFMA that needs them: one exposed L2 round trip per tile).  Two register sets, the quad
+        // loop is unrolled by two so that they swap roles without moves.
+        uint32_t a_off = half ? mf.n_quads * (uint32_t)(kMfQuadTiles * 512) + (uint32_t)col * 16u
+                              : q_begin * (uint32_t)(kMfQuadTiles * 512) + (uint32_t)col * 16u;
+        auto fetch_quad = [&](uint4 (&dst)[kMfQuadTiles]) {            // fetches the quad a_off points at, then advances
 #pragma unroll
-            for (int t = 0; t < kMfGroupTiles; ++t) {
-                dst[t] = make_uint4(0u, 0u, 0u, 0u);
-                if (!half && g < g_end) dst[t] = mf.A[((size_t)g * kMfGroupTiles + t) * 32 + col];   // whole groups are allocated
-            }
+            for (int t = 0; t < kMfQuadTiles; ++t) dst[t] = *reinterpret_cast<const uint4 *>(A_bytes + a_off + (uint32_t)(t * 512));
+            a_off += a_inc;                                            // the quad after the last one is the zero padding: in bounds
         };
-        fetch_group(g_begin, a_cur);
-        for (uint32_t g = g_begin; g < g_end; ++g) {
-            fetch_group(g + 1u, a_nxt);
-            const MfGroup G = mf.groups[g];                                   // wave-uniform: scalar loads
-            bf16x8 B[S];
-            float thresh[S];
-#pragma unroll
-            for (int s = 0; s < S; ++s) {
-                const MfRay &r = ray[s];
-                const f3 ol = r.o - mk(G.cx, G.cy, G.cz);
-                const f3 cvl = cross3(r.d, ol);
-                // v_sqrt_f32 (1 ulp) instead of the correctly rounded sequence: these are bounds, inflated by 1.001
-                const float ncv = __builtin_amdgcn_sqrtf(dot3(cvl, cvl)) * 1.001f, no = __builtin_amdgcn_sqrtf(dot3(ol, ol)) * 1.001f;
-                thresh[s] = r.valid ? -mf_margin(G, ncv, no, r) : __builtin_inff();          // empty slot: nothing survives
-                uint4 bw;
-                bw.x = half ? 0u : pack_bf16(cvl.x, cvl.y);
-                bw.y = half ? 0u : pack_bf16(cvl.z, r.d.x);
-                bw.z = r.dyz; bw.w = r.one;                                                   // k = 8..15 (upper lane half) is zero
-                B[s] = __builtin_bit_cast(bf16x8, bw);
-            }
-#pragma unroll
-            for (int t = 0; t < kMfGroupTiles; ++t) {
-                const uint32_t tile = g * kMfGroupTiles + t;
-                if (tile * kMfTileTris >= sc.n_tri_visits) break;                           // wave-uniform
-                const bf16x8 Aop = __builtin_bit_cast(bf16x8, a_cur[t]);
+        bf16x8 B[S];
+        float thresh[S];
+        auto step = [&](uint32_t q, uint4 (&a_cur)[kMfQuadTiles], uint4 (&a_nxt)[kMfQuadTiles]) {
+            fetch_quad(a_nxt);
+            if ((q & group_mask) == 0u) {                                     // first quad of a group: new local origin and bounds
+                const ConstFloats gp = groups_k + (size_t)(q >> group_shift) * (sizeof(MfGroup) / 4);   // wave-uniform: scalar loads
+                MfGroup G;
+                G.cx = gp[0]; G.cy = gp[1]; G.cz = gp[2]; G.E = gp[3]; G.Ml = gp[4]; G.Pw = gp[5]; G.P = gp[6]; G.pad1 = 0.0f;
 #pragma unroll
                 for (int s = 0; s < S; ++s) {
-                    f32x16 acc = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Aop, B[s], acc, 0, 0, 0);
-                    // five tests per lane: v_min3 + v_cmp each, the survivor masks stay in SGPRs and ONE scalar branch
-                    // skips the parking code (taken by ~1 step in 8)
-                    unsigned long long surv[5], any = 0;
+                    const MfRay &r = ray[s];
+                    const f3 ol = r.o - mk(G.cx, G.cy, G.cz);
+                    const f3 cvl = cross3(r.d, ol);
+                    // v_sqrt_f32 (1 ulp) instead of the correctly rounded sequence: these are bounds, inflated by 1.001
+                    const float ncv = __builtin_amdgcn_sqrtf(dot3(cvl, cvl)) * 1.001f, no = __builtin_amdgcn_sqrtf(dot3(ol, ol)) * 1.001f;
+                    const float margin = mf_margin(G, ncv, no, r);
+                    // empty slot: nothing survives.  Margin not finite or so large that the bf16 products could overflow
+                    // (bounds NaN for non-finite vertices, huge coordinates): NaN threshold, everything survives.
+                    thresh[s] = !r.valid ? __builtin_inff() : (margin < 1.0e30f ? -margin : __builtin_nanf(""));
+                    uint4 bw;
+                    bw.x = half ? 0u : pack_bf16(cvl.x, cvl.y);
+                    bw.y = half ? 0u : pack_bf16(cvl.z, r.d.x);
+                    bw.z = r.dyz; bw.w = r.one;                                               // k = 8..15 (upper lane half) is zero
+                    B[s] = __builtin_bit_cast(bf16x8, bw);
+                }
+            }
 #pragma unroll
-                    for (int u = 0; u < 5; ++u) {
-                        const float mn = __builtin_fminf(__builtin_fminf(acc[3 * u], acc[3 * u + 1]), acc[3 * u + 2]);
-                        surv[u] = __builtin_amdgcn_ballot_w64(!(mn <= thresh[s]));
-                        any |= surv[u];
-                    }
-                    if (any) {
+            for (int t = 0; t < kMfQuadTiles; ++t) {
+                const uint32_t tile = q * kMfQuadTiles + t;
+                if (tile * kMfTileTris >= n_tri_visits) break;                           // wave-uniform
+                const bf16x8 Aop = __builtin_bit_cast(bf16x8, a_cur[t]);
+                // all S products first (back to back on the matrix pipe), then five v_min3 per ray set and lane, and ONE
+                // compare on the max of the minima: the common "nothing survived" case costs 8 VALU + 1 branch per MFMA
+                f32x16 acc[S];
+                float mn[S][5];
+                bool any_lane = false;
+#pragma unroll
+                for (int s = 0; s < S; ++s) {
+                    const f32x16 zero = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+                    acc[s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Aop, B[s], zero, 0, 0, 0);
+                }
+#pragma unroll
+                for (int s = 0; s < S; ++s) {
+#pragma unroll
+                    for (int u = 0; u < 5; ++u) mn[s][u] = __builtin_fminf(__builtin_fminf(acc[s][3 * u], acc[s][3 * u + 1]), acc[s][3 * u + 2]);
+                    // A finite threshold means finite operands and edge values below 2^7 * 1e30 in magnitude, hence finite
+                    // minima: max-of-minima is then exactly "some triangle of this lane survives".  A NaN threshold passes all.
+                    const float mx = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(mn[s][0], mn[s][1]), mn[s][2]), mn[s][3]), mn[s][4]);   // two v_max3
+                    any_lane |= !(mx <= thresh[s]);
+                }
+                if (__builtin_amdgcn_ballot_w64(any_lane) != 0ull) {
+#pragma unroll
+                    for (int s = 0; s < S; ++s)
 #pragma unroll
                         for (int u = 0; u < 5; ++u) {
-                            const unsigned long long m = surv[u];
+                            const unsigned long long m = __builtin_amdgcn_ballot_w64(!(mn[s][u] <= thresh[s]));
                             if (m) {                                                        // wave-uniform
                                 if (qn > kQueue - 64u) flush();
                                 if ((m >> lane) & 1ull) {
@@ -249,11 +303,14 @@ __global__ void __launch_bounds__(256) intersect_mfma_kernel(SceneView sc, WaveB
                                 qn += (uint32_t)__popcll(m);
                             }
                         }
-                    }
                 }
             }
-#pragma unroll
-            for (int t = 0; t < kMfGroupTiles; ++t) a_cur[t] = a_nxt[t];
+        };
+        uint4 a0[kMfQuadTiles], a1[kMfQuadTiles];
+        fetch_quad(a0);
+        for (uint32_t q = q_begin; q < q_end; q += 2u) {
+            step(q, a0, a1);
+            if (q + 1u < q_end) step(q + 1u, a1, a0);
         }
         flush();
         const uint32_t n_cand = (lane == 0) ? n_total : 0u;

@@ -177,7 +177,7 @@ struct rtgl_context {
 
     // bounce-wavefront pipeline buffers
     float2 *d_group_bounds = nullptr;
-    MfGroup *d_mf_groups = nullptr; uint4 *d_mf_A = nullptr; uint32_t *d_mf_order = nullptr; uint32_t n_mf_groups = 0;   // bf16 matrix-core broad phase
+    MfGroup *d_mf_groups = nullptr; uint4 *d_mf_A = nullptr; uint32_t *d_mf_order = nullptr; uint32_t n_mf_groups = 0, mf_group_quads = 2;   // bf16 matrix-core broad phase
     void *d_wave = nullptr; size_t wave_capacity = 0; bool wave_multi = false;   // queues (+ per-pixel state when u_samples > 1)
     uint32_t *d_counts = nullptr; uint32_t counts_capacity = 0;
     uint32_t *h_counts = nullptr;            // pinned: ray counts per bounce of the most recent finished frame
@@ -189,7 +189,7 @@ struct rtgl_context {
     bool tris_dirty = false, visits_dirty = false;
     FrameParams params{};
     bool have_params = false;
-    int opt_kernel = RTGL_KERNEL_WAVEFRONT_SPLIT, opt_rng_state = 0, opt_counters = 0, opt_kernel_timing = 0, opt_wf_rays = 4, opt_wf_mode = kLds, opt_wf_chunk = 256, opt_wf_early = 0, opt_wf_packed = 0, opt_mf_sets = 2, opt_mf_chunk_groups = 64, opt_debug_skip_exact = 0;
+    int opt_kernel = RTGL_KERNEL_WAVEFRONT_SPLIT, opt_rng_state = 0, opt_counters = 0, opt_kernel_timing = 0, opt_wf_rays = 4, opt_wf_mode = kLds, opt_wf_chunk = 256, opt_wf_early = 0, opt_wf_packed = 0, opt_mf_sets = 2, opt_mf_chunk_quads = 64, opt_mf_group_quads = 2, opt_debug_skip_exact = 0;
 };
 
 static int fail(rtgl_context *ctx, int code, const std::string &msg)
@@ -444,14 +444,19 @@ static int rebuild_triangles(rtgl_context *ctx)
         if (ctx->d_mf_groups) { HIPCHK(ctx, hipFree(ctx->d_mf_groups)); ctx->d_mf_groups = nullptr; }
         if (ctx->d_mf_A) { HIPCHK(ctx, hipFree(ctx->d_mf_A)); ctx->d_mf_A = nullptr; }
         if (ctx->d_mf_order) { HIPCHK(ctx, hipFree(ctx->d_mf_order)); ctx->d_mf_order = nullptr; }
-        ctx->n_mf_groups = (ctx->n_tri_visits + kMfGroupTris - 1) / kMfGroupTris;
+        ctx->mf_group_quads = (uint32_t)ctx->opt_mf_group_quads;
+        const uint32_t group_tris = ctx->mf_group_quads * kMfQuadTris;
+        ctx->n_mf_groups = (ctx->n_tri_visits + group_tris - 1) / group_tris;
         const std::vector<uint32_t> order = morton_order(ctx, visit_tri);
         HIPCHK(ctx, hipMalloc((void **)&ctx->d_mf_order, order.size() * 4));
         HIPCHK(ctx, hipMemcpyAsync(ctx->d_mf_order, order.data(), order.size() * 4, hipMemcpyHostToDevice, ctx->stream));
         HIPCHK(ctx, hipMalloc((void **)&ctx->d_mf_groups, (size_t)ctx->n_mf_groups * sizeof(MfGroup)));
-        HIPCHK(ctx, hipMalloc((void **)&ctx->d_mf_A, (size_t)ctx->n_mf_groups * kMfGroupTiles * 32 * sizeof(uint4)));
+        const size_t a_bytes = ((size_t)ctx->n_mf_groups * ctx->mf_group_quads + 1) * kMfQuadTiles * 32 * sizeof(uint4);   // + one zero quad
+        if (a_bytes > 0xFFFF0000ull) return fail(ctx, RTGL_ERR_INVALID, "mesh too large for the 32-bit tile offsets of the kernel-3 scan");
+        HIPCHK(ctx, hipMalloc((void **)&ctx->d_mf_A, a_bytes));
+        HIPCHK(ctx, hipMemsetAsync(ctx->d_mf_A, 0, a_bytes, ctx->stream));
         hipLaunchKernelGGL(prepare_mfma_kernel, dim3((ctx->n_mf_groups + 63) / 64), dim3(64), 0, ctx->stream, ctx->d_vertices, d_visit,
-                           ctx->d_mf_order, ctx->n_tri_visits, ctx->n_mf_groups, ctx->d_mf_groups, ctx->d_mf_A);
+                           ctx->d_mf_order, ctx->n_tri_visits, ctx->n_mf_groups, ctx->mf_group_quads, ctx->d_mf_groups, ctx->d_mf_A);
         HIPCHK(ctx, hipGetLastError());
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
         HIPCHK(ctx, hipFree(d_visit));
@@ -544,14 +549,16 @@ static void launch_intersect(rtgl_context *ctx, const SceneView &sc, uint32_t n0
 template <int S>
 static void launch_intersect_mfma(rtgl_context *ctx, const SceneView &sc, uint32_t n0, uint32_t bounce)
 {
-    const uint32_t chunk_groups = (uint32_t)ctx->opt_mf_chunk_groups;
+    const uint32_t gq = ctx->mf_group_quads, n_quads = ctx->n_mf_groups * gq;
+    uint32_t chunk_quads = ((uint32_t)ctx->opt_mf_chunk_quads + gq - 1) / gq * gq;             // whole groups per chunk
+    if (chunk_quads > kMfMaxChunkQuads) chunk_quads = kMfMaxChunkQuads / gq * gq;
     const uint32_t est = estimate_rays(ctx, n0, bounce), rays_per_block = 4u * S * 32u;
-    dim3 grid((est + rays_per_block - 1) / rays_per_block, (ctx->n_mf_groups + chunk_groups - 1) / chunk_groups);
-    MfView mf{ctx->d_mf_groups, ctx->n_mf_groups, ctx->d_mf_A, ctx->d_mf_order};
+    dim3 grid((est + rays_per_block - 1) / rays_per_block, (n_quads + chunk_quads - 1) / chunk_quads);
+    MfView mf{ctx->d_mf_groups, ctx->n_mf_groups, gq, n_quads, ctx->d_mf_A, ctx->d_mf_order};
     if (ctx->opt_counters)
-        hipLaunchKernelGGL((intersect_mfma_kernel<S, true>), grid, dim3(256), 0, ctx->stream, sc, ctx->wb, mf, bounce, chunk_groups, ctx->d_counters, ctx->opt_debug_skip_exact);
+        hipLaunchKernelGGL((intersect_mfma_kernel<S, true>), grid, dim3(256), 0, ctx->stream, sc, ctx->wb, mf, bounce, chunk_quads, ctx->d_counters, ctx->opt_debug_skip_exact);
     else
-        hipLaunchKernelGGL((intersect_mfma_kernel<S, false>), grid, dim3(256), 0, ctx->stream, sc, ctx->wb, mf, bounce, chunk_groups, ctx->d_counters, ctx->opt_debug_skip_exact);
+        hipLaunchKernelGGL((intersect_mfma_kernel<S, false>), grid, dim3(256), 0, ctx->stream, sc, ctx->wb, mf, bounce, chunk_quads, ctx->d_counters, ctx->opt_debug_skip_exact);
 }
 
 static int launch_wavefront(rtgl_context *ctx, const SceneView &sc, const FrameParams &P, const ImageView &im, uint32_t n0, uint4 *rng_out)
@@ -859,9 +866,13 @@ extern "C" int rtgl_set_option(rtgl_context *ctx, const char *key, int value)
     } else if (!strcmp(key, "mf_sets")) {
         if (value != 2 && value != 4) return fail(ctx, RTGL_ERR_INVALID, "mf_sets must be 2 or 4");
         ctx->opt_mf_sets = value;
-    } else if (!strcmp(key, "mf_chunk_groups")) {
-        if (value < 1 || (uint32_t)value * kMfGroupTiles > kMfMaxChunkTiles) return fail(ctx, RTGL_ERR_INVALID, "mf_chunk_groups must be in [1, 128]");
-        ctx->opt_mf_chunk_groups = value;
+    } else if (!strcmp(key, "mf_chunk_quads")) {
+        if (value < 1 || (uint32_t)value > kMfMaxChunkQuads) return fail(ctx, RTGL_ERR_INVALID, "mf_chunk_quads must be in [1, 128]");
+        ctx->opt_mf_chunk_quads = value;
+    } else if (!strcmp(key, "mf_group_quads")) {
+        if (value != 1 && value != 2 && value != 4 && value != 8 && value != 16) return fail(ctx, RTGL_ERR_INVALID, "mf_group_quads must be 1, 2, 4, 8 or 16");
+        if (value != ctx->opt_mf_group_quads) ctx->tris_dirty = true;                          // local origins and A tiles are per group
+        ctx->opt_mf_group_quads = value;
     } else if (!strcmp(key, "wf_packed")) {
         ctx->opt_wf_packed = value != 0;
     } else if (!strcmp(key, "wf_early")) {
@@ -890,7 +901,8 @@ extern "C" int rtgl_get_option(rtgl_context *ctx, const char *key, int *value)
     else if (!strcmp(key, "wf_early")) *value = ctx->opt_wf_early;
     else if (!strcmp(key, "wf_packed")) *value = ctx->opt_wf_packed;
     else if (!strcmp(key, "mf_sets")) *value = ctx->opt_mf_sets;
-    else if (!strcmp(key, "mf_chunk_groups")) *value = ctx->opt_mf_chunk_groups;
+    else if (!strcmp(key, "mf_chunk_quads")) *value = ctx->opt_mf_chunk_quads;
+    else if (!strcmp(key, "mf_group_quads")) *value = ctx->opt_mf_group_quads;
     else if (!strcmp(key, "rng_state")) *value = ctx->opt_rng_state;
     else if (!strcmp(key, "counters")) *value = ctx->opt_counters;
     else if (!strcmp(key, "kernel_timing")) *value = ctx->opt_kernel_timing;

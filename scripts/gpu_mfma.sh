@@ -1,7 +1,7 @@
 set -e
 mkdir -p gpurun_out
 make -s -C oracle liboracle.so
-timeout -k 10 600 python -m pytest tests/test_gpu_parity.py tests/test_gpu_golden.py -m gpu -x -q 2>&1 | tail -3
+timeout -k 10 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_golden.py -m gpu -x -q 2>&1 | tail -3
 run() {
 timeout -k 10 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline "$@" > gpurun_out/ab.json 2> gpurun_out/ab.err || (tail -5 gpurun_out/ab.err; exit 1)
 python - "$@" <<'PY'
@@ -9,9 +9,12 @@ import json,sys; d=json.load(open('gpurun_out/ab.json')); print(" ".join(sys.arg
 PY
 }
 run --kernel 2
-run --kernel 3 --mf-sets 2
-run --kernel 3 --mf-sets 4
-run --kernel 3 --mf-sets 2 --debug-skip-exact 1
-run --kernel 3 --mf-sets 2 --mf-chunk-groups 128
-run --kernel 3 --mf-sets 4 --mf-chunk-groups 128
-run --kernel 3 --mf-sets 2 --mf-chunk-groups 32
+run --kernel 3 --mf-group-quads 1
+run --kernel 3 --mf-group-quads 2
+run --kernel 3 --mf-group-quads 4
+run --kernel 3 --mf-group-quads 8
+run --kernel 3 --mf-group-quads 16
+run --kernel 3 --mf-group-quads 4 --mf-sets 4
+run --kernel 3 --mf-group-quads 8 --mf-sets 4
+run --kernel 3 --mf-group-quads 4 --mf-chunk-quads 32
+run --kernel 3 --mf-group-quads 4 --mf-chunk-quads 128

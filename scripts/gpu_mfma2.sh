@@ -8,6 +8,6 @@ PY
 }
 run --kernel 3
 run --kernel 3 --debug-skip-exact 1
-run --kernel 3 --mf-chunk-groups 16
-run --kernel 3 --mf-chunk-groups 16 --debug-skip-exact 1
+run --kernel 3 --mf-chunk-quads 16
+run --kernel 3 --mf-chunk-quads 16 --debug-skip-exact 1
 bash scripts/gpu_profile.sh r1_mfma_c2 --kernel 3

@@ -37,7 +37,7 @@ def test_default_kernel_matches_reference_shader_output(path, rt):
 def test_matrix_core_broad_phase_matches_reference_shader_output(path, rt):
     """kernel 3: bf16 MFMA rejects, the exact reference-order test decides -- every golden case, bit for bit."""
     meta, scene, frames, expected = load_case(path, rt)
-    img = render_case(rt, meta, scene, frames, options=(("kernel", 3), ("mf_chunk_groups", 2)))
+    img = render_case(rt, meta, scene, frames, options=(("kernel", 3), ("mf_chunk_quads", 2), ("mf_group_quads", 2)))
     neq = (img.view(np.uint32) != expected.view(np.uint32)).any(axis=2)
     assert not neq.any(), f"{int(neq.sum())} of {neq.size} pixels differ from the reference shader's output"
 
