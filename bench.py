@@ -80,6 +80,7 @@ def main():
     ap.add_argument("--mf-sets", type=int, default=None, help="kernel 3: 32-ray sets per wave (2 or 4)")
     ap.add_argument("--mf-chunk-quads", type=int, default=None, help="kernel 3: 40-triangle quads per work item")
     ap.add_argument("--mf-group-quads", type=int, default=None, help="kernel 3: quads sharing one local origin (1, 2, 4, 8, 16)")
+    ap.add_argument("--debug-bounces", type=int, default=None, help="diagnostic: override the bounce limit of the configuration (not the named workload)")
     ap.add_argument("--strip-rows", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sync-each-frame", action="store_true", help="diagnostic: host waits for every frame")
@@ -110,6 +111,8 @@ def main():
     W, H = cfg["width"], cfg["height"]
     scene = cfg["scene"]()
     base = cfg["params"]()
+    if args.debug_bounces is not None:
+        base.max_bounce = args.debug_bounces
 
     ctx = rt.host.Context(W, H, device=local_rank, rank=rank, world=world, strip_rows=args.strip_rows)
     ctx.upload_scene(scene)

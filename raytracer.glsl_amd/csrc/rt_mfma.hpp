@@ -256,7 +256,7 @@ __global__ void __launch_bounds__(256) intersect_mfma_kernel(SceneView sc, WaveB
                     const float margin = mf_margin(G, ncv, no, r);
                     // empty slot: nothing survives.  Margin not finite or so large that the bf16 products could overflow
                     // (bounds NaN for non-finite vertices, huge coordinates): NaN threshold, everything survives.
-                    thresh[s] = !r.valid ? __builtin_inff() : (margin < 1.0e30f ? -margin : __builtin_nanf(""));
+                    thresh[s] = (!r.valid || debug_skip_exact == 2) ? __builtin_inff() : (margin < 1.0e30f ? -margin : __builtin_nanf(""));
                     uint4 bw;
                     bw.x = half ? 0u : pack_bf16(cvl.x, cvl.y);
                     bw.y = half ? 0u : pack_bf16(cvl.z, r.d.x);

@@ -177,7 +177,7 @@ struct rtgl_context {
 
     // bounce-wavefront pipeline buffers
     float2 *d_group_bounds = nullptr;
-    MfGroup *d_mf_groups = nullptr; uint4 *d_mf_A = nullptr; uint32_t *d_mf_order = nullptr; uint32_t n_mf_groups = 0, mf_group_quads = 2;   // bf16 matrix-core broad phase
+    MfGroup *d_mf_groups = nullptr; uint4 *d_mf_A = nullptr; uint32_t *d_mf_order = nullptr; uint32_t n_mf_groups = 0, mf_group_quads = 4;   // bf16 matrix-core broad phase
     void *d_wave = nullptr; size_t wave_capacity = 0; bool wave_multi = false;   // queues (+ per-pixel state when u_samples > 1)
     uint32_t *d_counts = nullptr; uint32_t counts_capacity = 0;
     uint32_t *h_counts = nullptr;            // pinned: ray counts per bounce of the most recent finished frame
@@ -189,7 +189,7 @@ struct rtgl_context {
     bool tris_dirty = false, visits_dirty = false;
     FrameParams params{};
     bool have_params = false;
-    int opt_kernel = RTGL_KERNEL_WAVEFRONT_SPLIT, opt_rng_state = 0, opt_counters = 0, opt_kernel_timing = 0, opt_wf_rays = 4, opt_wf_mode = kLds, opt_wf_chunk = 256, opt_wf_early = 0, opt_wf_packed = 0, opt_mf_sets = 2, opt_mf_chunk_quads = 64, opt_mf_group_quads = 2, opt_debug_skip_exact = 0;
+    int opt_kernel = RTGL_KERNEL_WAVEFRONT_SPLIT, opt_rng_state = 0, opt_counters = 0, opt_kernel_timing = 0, opt_wf_rays = 4, opt_wf_mode = kLds, opt_wf_chunk = 256, opt_wf_early = 0, opt_wf_packed = 0, opt_mf_sets = 2, opt_mf_chunk_quads = 64, opt_mf_group_quads = 4, opt_debug_skip_exact = 0;
 };
 
 static int fail(rtgl_context *ctx, int code, const std::string &msg)
@@ -379,7 +379,8 @@ static int rebuild_sphere_visits(rtgl_context *ctx)
 }
 
 // Storage order of the triangle visits for the matrix-core broad phase: sorted by the Morton code of the triangle
-// centroid (10 bits per axis over the bounding box of all centroids), ties by visit index.  Only tightness of the
+// centroid (10 bits per axis, ONE scale for all three axes: cells must be cubes in world space or a height field gets cut
+// into contour strips), ties by visit index.  Only tightness of the
 // per-group bounds depends on it; non-finite centroids simply land in cell 0.
 static std::vector<uint32_t> morton_order(const rtgl_context *ctx, const std::vector<uint32_t> &visit_tri)
 {
@@ -396,10 +397,11 @@ static std::vector<uint32_t> morton_order(const rtgl_context *ctx, const std::ve
         }
     auto spread = [](uint64_t x) { x &= 0x3ff; x = (x | (x << 16)) & 0x30000ff; x = (x | (x << 8)) & 0x300f00f; x = (x | (x << 4)) & 0x30c30c3; x = (x | (x << 2)) & 0x9249249; return x; };
     std::vector<std::pair<uint64_t, uint32_t>> keyed(n);
+    const float ext = std::max(hi[0] - lo[0], std::max(hi[1] - lo[1], hi[2] - lo[2]));
     for (size_t v = 0; v < n; ++v) {
         uint64_t code = 0;
         for (int a = 0; a < 3; ++a) {
-            const float c = cen[3 * v + a], ext = hi[a] - lo[a];
+            const float c = cen[3 * v + a];
             uint64_t q = 0;
             if (c == c && ext > 0.0f && c >= lo[a] && c <= hi[a]) q = (uint64_t)std::min(1023.0f, (c - lo[a]) / ext * 1023.0f);
             code |= spread(q) << a;
@@ -862,7 +864,7 @@ extern "C" int rtgl_set_option(rtgl_context *ctx, const char *key, int value)
         if (value < kBoundGroup || value % kBoundGroup || (uint32_t)value > kMaxChunk) return fail(ctx, RTGL_ERR_INVALID, "wf_chunk must be a multiple of 64 in [64, 4096]");
         ctx->opt_wf_chunk = value;
     } else if (!strcmp(key, "debug_skip_exact")) {      // timing diagnostics only: the image is wrong
-        ctx->opt_debug_skip_exact = value != 0;
+        ctx->opt_debug_skip_exact = value;               // 1: no exact narrow phase; 2: broad phase rejects everything
     } else if (!strcmp(key, "mf_sets")) {
         if (value != 2 && value != 4) return fail(ctx, RTGL_ERR_INVALID, "mf_sets must be 2 or 4");
         ctx->opt_mf_sets = value;

@@ -34,7 +34,7 @@ json.dump(out, open(f"{dst}/pmc_summary.json", "w"), indent=1)
 # dominant kernel (largest total time in the kernel-trace stats)
 stats = list(csv.DictReader(open(f"{dst}/kernel_stats.csv")))
 dom = max(stats, key=lambda r: float(r["TotalDurationNs"]))["Name"].split("(")[0]
-short = "intersect_kernel" if "intersect_kernel" in dom else "bounce_kernel" if "bounce_kernel" in dom else "pathtrace_mega_kernel"
+short = "intersect_mfma_kernel" if "intersect_mfma_kernel" in dom else "intersect_kernel" if "intersect_kernel" in dom else "bounce_kernel" if "bounce_kernel" in dom else "pathtrace_mega_kernel"
 fetch = sum(v["FETCH_SIZE"] for k, v in out["pmc_fetch"].items() if short in k)
 fcalls = sum(v["calls"] for k, v in out["pmc_fetch"].items() if short in k)
 write = sum(v["WRITE_SIZE"] for k, v in out["pmc_write"].items() if short in k)
