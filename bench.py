@@ -22,6 +22,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 FP32_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: peak FP32 vector
+BF16_DENSE_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense bf16 matrix peak (the headline 5 PF figure includes 2:1 sparsity)
 
 
 def scene_bytes(scene) -> int:
@@ -190,6 +191,21 @@ def main():
         kname = {0: "pathtrace_mega_kernel", 1: "bounce_kernel", 2: "intersect_kernel", 3: "intersect_mfma_kernel"}[ctx.get_option("kernel")]
         if scan_launches == 0:
             kname = "whole frame (generate_rays + shade)"
+        k = ctx.get_option("kernel")
+        gtests = cnt["triangle_tests"] * share / launches_per_frame / avg_launch_s / 1e9
+        tflops = flops_per_launch / avg_launch_s / 1e12
+        if k == 3:
+            # bf16 matrix pipe for the conservative broad phase + fp32 VALU for thresholds/minima; both issue from the same
+            # SIMD port and do not overlap (tools/mfma_bf16_valu_rate.hip), so the practical ceiling is the measured issue
+            # floor of "one 32x32x16 MFMA + 5 v_min3 + 2 v_max3" = 22 ns per SIMD per 320 tests
+            floor_gtests = 320.0 / 22.0e-9 * 1024 / 1e9
+            compute = {"pipe": "bf16 MFMA broad phase + fp32 VALU (one issue port per SIMD)", "achieved": tflops, "peak": BF16_DENSE_PEAK_TFLOPS,
+                       "unit": "TFLOP/s", "frac": tflops / BF16_DENSE_PEAK_TFLOPS, "flop_per_test": 36, "gtests_per_s": gtests,
+                       "issue_floor_gtests_per_s": floor_gtests, "frac_of_issue_floor": gtests / floor_gtests,
+                       "scan_share_of_frame": scan_ms / max(frame_ms, 1e-9)}
+        else:
+            compute = {"pipe": "fp32 VALU", "achieved": tflops, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / FP32_PEAK_TFLOPS,
+                       "flop_per_test": 36, "gtests_per_s": gtests, "scan_share_of_frame": scan_ms / max(frame_ms, 1e-9)}
         traffic = None
         tf = os.path.join(ROOT, "profiles", "hbm_traffic.json")     # written by scripts/gpu_profile.sh (rocprofv3 PMC passes)
         if os.path.exists(tf):
@@ -205,16 +221,14 @@ def main():
                                    f"{scene.spheres.shape[0]} spheres, cube map {scene.env.shape[1] if scene.env is not None else 0}^2, "
                                    f"1 spp/frame progressive, dof={base.use_dof}",
                        "parallelism": f"{world} GPU(s), {args.strip_rows}-row strips interleaved, gather to rank 0 every frame",
-                       "kernel": ctx.get_option("kernel"), "wf_rays": ctx.get_option("wf_rays"), "wf_mode": ctx.get_option("wf_mode"), "wf_chunk": ctx.get_option("wf_chunk"), "wf_early": ctx.get_option("wf_early"), "wf_packed": ctx.get_option("wf_packed")},
+                       "kernel": ctx.get_option("kernel"), "wf_rays": ctx.get_option("wf_rays"), "wf_mode": ctx.get_option("wf_mode"), "wf_chunk": ctx.get_option("wf_chunk"), "wf_early": ctx.get_option("wf_early"), "wf_packed": ctx.get_option("wf_packed"),
+                       "mf_sets": ctx.get_option("mf_sets"), "mf_group_quads": ctx.get_option("mf_group_quads"), "mf_chunk_quads": ctx.get_option("mf_chunk_quads")},
             "roofline": {"bound": "hbm", "achieved": bytes_per_launch / avg_launch_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": bytes_per_launch / avg_launch_s / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": kname, "launches_per_frame": launches_per_frame, "avg_launch_ms": avg_launch_s * 1e3,
                          "algorithmic_bytes_per_launch": bytes_per_launch,
-                         "note": "brute-force ray x triangle scan is fp32-VALU-bound (see valu); HBM fraction is small by construction"},
-            "valu": {"achieved": flops_per_launch / avg_launch_s / 1e12, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": flops_per_launch / avg_launch_s / 1e12 / FP32_PEAK_TFLOPS,
-                     "gtests_per_s": cnt["triangle_tests"] * share / launches_per_frame / avg_launch_s / 1e9,
-                     "scan_share_of_frame": scan_ms / max(frame_ms, 1e-9)},
+                         "note": "brute-force ray x triangle scan is bound by vector/matrix issue, not memory (see compute); HBM fraction is small by construction"},
+            "compute": compute,
             "counters_per_frame": cnt,
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -91,7 +91,7 @@ def test_c4_100k_triangles_variants_agree_and_match_oracle_strip(rt, oracle):
     a, cnt, _, scene, plist = render(rt, "C4", frames=1, counters=True)
     b = render(rt, "C4", frames=1, options=(("kernel", 2), ("wf_mode", 0), ("wf_rays", 4)))[0]
     assert (a.view(np.uint32) == b.view(np.uint32)).all()
-    c = render(rt, "C4", frames=1, options=(("kernel", 3),))[0]
+    c = render(rt, "C4", frames=1, options=(("kernel", 2),))[0]
     assert (a.view(np.uint32) == c.view(np.uint32)).all()
     assert cnt["triangle_tests"] == cnt["segments"] * 100000
     want = np.zeros_like(a)
@@ -104,7 +104,7 @@ def test_c5_2160p_16_bounces_wide_dof(rt, oracle):
     assert cnt["paths"] == 3840 * 2160 and cnt["segments"] <= cnt["paths"] * 16
     b = render(rt, "C5", frames=1, options=(("kernel", 1), ("wf_mode", 1), ("wf_rays", 2)))[0]
     assert (a.view(np.uint32) == b.view(np.uint32)).all()
-    c = render(rt, "C5", frames=1, options=(("kernel", 3),))[0]
+    c = render(rt, "C5", frames=1, options=(("kernel", 2),))[0]
     assert (a.view(np.uint32) == c.view(np.uint32)).all()
     want = np.zeros_like(a)
     oracle.render(scene, plist[0], want, rect=(0, 1080, 3840, 1084), threads=16)

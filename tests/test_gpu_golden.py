@@ -27,19 +27,28 @@ def render_case(rt, meta, scene, frames, options=()):
 
 @pytest.mark.parametrize("path", CASE_FILES, ids=lambda p: os.path.basename(p)[:-4])
 def test_default_kernel_matches_reference_shader_output(path, rt):
+    """library defaults (kernel 3, 4 quads per group, 64-quad chunks) -- every golden case, bit for bit."""
     meta, scene, frames, expected = load_case(path, rt)
-    img = render_case(rt, meta, scene, frames, options=(("wf_chunk", 128),))
+    img = render_case(rt, meta, scene, frames)
     neq = (img.view(np.uint32) != expected.view(np.uint32)).any(axis=2)
     assert not neq.any(), f"{int(neq.sum())} of {neq.size} pixels differ from the reference shader's output"
 
 
 @pytest.mark.parametrize("path", CASE_FILES, ids=lambda p: os.path.basename(p)[:-4])
-def test_matrix_core_broad_phase_matches_reference_shader_output(path, rt):
-    """kernel 3: bf16 MFMA rejects, the exact reference-order test decides -- every golden case, bit for bit."""
+def test_matrix_core_broad_phase_small_chunks_matches_reference_shader_output(path, rt):
+    """kernel 3 with chunks and groups small enough that the small golden meshes span several of each."""
     meta, scene, frames, expected = load_case(path, rt)
     img = render_case(rt, meta, scene, frames, options=(("kernel", 3), ("mf_chunk_quads", 2), ("mf_group_quads", 2)))
     neq = (img.view(np.uint32) != expected.view(np.uint32)).any(axis=2)
     assert not neq.any(), f"{int(neq.sum())} of {neq.size} pixels differ from the reference shader's output"
+
+
+@pytest.mark.parametrize("path", CASE_FILES, ids=lambda p: os.path.basename(p)[:-4])
+def test_fp32_scan_kernel_matches_reference_shader_output(path, rt):
+    """kernel 2: fp32 VALU filter + exact test (the variant without matrix cores) -- every golden case, bit for bit."""
+    meta, scene, frames, expected = load_case(path, rt)
+    img = render_case(rt, meta, scene, frames, options=(("kernel", 2), ("wf_chunk", 128)))
+    assert (img.view(np.uint32) == expected.view(np.uint32)).all()
 
 
 @pytest.mark.parametrize("kernel", [0, 1])
