@@ -5,21 +5,25 @@
 // i.e. a (3 N_tri) x 6 by 6 x N_ray matrix product.  The fp32 VALU scan (rt_wavefront.hpp) spends 20 vector
 // instructions per test on it and is bound by the FP32 datapath (the exact-f32 MFMA shares that datapath,
 // tools/mfma_valu_rate.hip).  The bf16 matrix pipe does the same contraction 16x faster but only with 8-bit
-// mantissas -- far too coarse to DECIDE a hit, yet enough to REJECT almost everything conservatively:
+// significands -- far too coarse to DECIDE a hit, yet enough to REJECT almost everything conservatively:
 //
-//   * triangles are grouped 40 at a time (4 MFMA tiles of 10 triangles = 30 edge rows + 2 spare) around a
+//   * triangles are stored in Morton order and grouped (1..16 "quads" of 4 MFMA tiles x 10 triangles) around a
 //     local origin c, so Plucker magnitudes are those of the neighbourhood, not of the world origin;
-//   * per (ray, group) the lane computes cv' = d x (o - c) in fp32, packs (cv', d, 1, 0) to bf16 (B operand)
-//     and a threshold = -(bf16 error bound + fp32 bounds), see margin() below;
-//   * one v_mfma_f32_32x32x16_bf16 per (tile, 32 rays) yields the 30 edge values of 10 triangles for each ray
-//     (fp32 accumulate); a triangle survives unless min(F0,F1,F2) <= threshold;
-//   * survivors (a few per ray over the whole mesh) are parked in LDS and afterwards run through the exact
-//     reference-order test (tri_exact), whose hits merge by the same 64-bit atomicMin as the fp32 scan.
+//   * per (ray, group) the lane computes cv' = d x (o - c) in fp32, packs it to bf16 (B operand) and computes a
+//     threshold = -(bf16 error bound + fp32 bounds), see mf_margin() below;
+//   * v_mfma_f32_32x32x16_bf16 has K = 16 but the contraction only needs 7 slots (6 + a bias that keeps padding
+//     rows out), so the other 9 carry the bf16 RESIDUALS of the precomputed side and of d: the triangle
+//     coefficients and the ray direction enter with 16-bit significands, only cv' stays at 8 bits (K layout at
+//     MfView).  This cuts the error bound -- and with it the survivors -- by ~2.5x at no extra matrix work;
+//   * one MFMA per (tile, 32 rays) yields the 30 edge values of 10 triangles for each ray (fp32 accumulate); a
+//     triangle survives unless min(F0,F1,F2) <= threshold;
+//   * survivors (a few per ray over the whole mesh) are queued in LDS and run through the exact reference-order
+//     test (tri_exact), whose hits merge by the same 64-bit atomicMin as the fp32 scan.
 //
 // Exactness: a triangle the reference accepts has exact edge values F_k > -(rounding of the reference's own
-// evaluation); the bf16 value differs from the exact one by at most margin_local (derivation at margin());
+// evaluation); the bf16 value differs from the exact one by at most the local bound (derivation at mf_margin());
 // so it can never fall under the threshold.  What the broad phase lets through is irrelevant to the result:
-// every survivor gets the exact test.  NaN / inf anywhere make `mn <= threshold` false => survive.
+// every survivor gets the exact test.  NaN / inf anywhere make the threshold NaN => everything survives.
 #pragma once
 #include "rt_wavefront.hpp"
 
@@ -34,7 +38,7 @@ constexpr int kMfTileTris = 10;                         // 2 lane-halves x 5 tri
 constexpr int kMfQuadTiles = 4;                         // tiles fetched together (one "quad" = 40 triangles)
 constexpr int kMfQuadTris = kMfTileTris * kMfQuadTiles;
 constexpr uint32_t kMfMaxChunkQuads = 128;              // queued entry keeps the triangle offset inside the chunk in 16 bits
-constexpr uint32_t kMfMaxGroupQuads = 16;               // a group = 1, 2, 4, 8 or 16 quads sharing one local origin and one set of bounds
+constexpr uint32_t kMfMaxGroupQuads = 64;               // a group = 1, 2, 4 .. 64 quads sharing one local origin and one set of bounds
 
 struct alignas(16) MfGroup {
     float cx, cy, cz;   // local origin (centre of the group's bounding box)
@@ -49,7 +53,12 @@ struct MfView {
     const MfGroup *groups; uint32_t n_groups;
     uint32_t group_quads;    // quads per group (power of two); storage is allocated in whole groups
     uint32_t n_quads;        // = n_groups * group_quads
-    const uint4 *A;          // per tile: 32 rows x 8 bf16 (e.x e.y e.z m'.x m'.y m'.z bias 0), row-major; n_quads quads + one all-zero quad
+    // A: per tile two 32-row x 8-bf16 panels (1 KiB), n_quads quads + one all-zero quad.  With x_hi = bf16(x) and
+    // x_lo = bf16(x - x_hi), the K slots of a triangle-edge row and the matching B entries of a ray are
+    //   panel 0 (k 0..7,  lanes 0-31):  e_hi.x e_hi.y e_hi.z  m_hi.x m_hi.y m_hi.z  bias  m_hi.x     x   cv.x cv.y cv.z  d_hi.x d_hi.y d_hi.z  1  d_lo.x
+    //   panel 1 (k 8..15, lanes 32-63): e_lo.x e_lo.y e_lo.z  m_lo.x m_lo.y m_lo.z  m_hi.y m_hi.z    x   cv.x cv.y cv.z  d_hi.x d_hi.y d_hi.z  d_lo.y d_lo.z
+    // i.e. F~ = (e_hi + e_lo).cv_hi + (m_hi + m_lo).d_hi + m_hi.d_lo  (+ bias, -3e38 on padding rows, 0 otherwise)
+    const uint4 *A;
     const uint32_t *order;   // storage position -> visit index.  Triangles are stored in Morton order of their centroids
                              // so that the triangles of a group are neighbours (tight local bounds); hits are merged by VISIT
                              // index, so the reference's first-visited-wins tie rule (:349) is unaffected by the reordering
@@ -78,10 +87,10 @@ __global__ void __launch_bounds__(64) prepare_mfma_kernel(const float4 *__restri
         }
     const f3 c = mk(0.5f * lo.x + 0.5f * hi.x, 0.5f * lo.y + 0.5f * hi.y, 0.5f * lo.z + 0.5f * hi.z);
     float E = 0.0f, Ml = 0.0f, Pw = 0.0f, P = 0.0f;
-    __bf16 *rows = reinterpret_cast<__bf16 *>(A + (size_t)g * group_tiles * 32);        // [tile][row][8]
-    for (uint32_t i = 0; i < group_tiles * 32 * 8; ++i) rows[i] = (__bf16)0.0f;
+    __bf16 *rows = reinterpret_cast<__bf16 *>(A + (size_t)g * group_tiles * 64);        // [tile][panel][row][8]
+    for (uint32_t i = 0; i < group_tiles * 64 * 8; ++i) rows[i] = (__bf16)0.0f;
     for (uint32_t t = 0; t < group_tiles; ++t)
-        for (int r = 0; r < 32; ++r) rows[(t * 32 + r) * 8 + 6] = (__bf16)(-3.0e38f);      // spare rows / missing triangles never survive
+        for (int r = 0; r < 32; ++r) rows[(t * 64 + r) * 8 + 6] = (__bf16)(-3.0e38f);      // spare rows / missing triangles never survive
     for (uint32_t v = v_begin; v < v_end; ++v) {
         const uint32_t tri = visit_tri[order[v]];                       // v = storage position
         f3 w[3], wl[3];
@@ -96,10 +105,16 @@ __global__ void __launch_bounds__(64) prepare_mfma_kernel(const float4 *__restri
             Ml = fmaxf(Ml, __builtin_sqrtf(dot3(ml, ml)));
             P = fmaxf(P, __builtin_sqrtf(dot3(wl[a], wl[a])) * __builtin_sqrtf(dot3(wl[k], wl[k])));
             Pw = fmaxf(Pw, __builtin_sqrtf(dot3(w[a], w[a])) * __builtin_sqrtf(dot3(w[k], w[k])));
-            __bf16 *row = rows + ((size_t)tile * 32 + mf_row(3 * u + k, h)) * 8;
-            row[0] = (__bf16)e.x; row[1] = (__bf16)e.y; row[2] = (__bf16)e.z;
-            row[3] = (__bf16)ml.x; row[4] = (__bf16)ml.y; row[5] = (__bf16)ml.z;
-            row[6] = (__bf16)0.0f; row[7] = (__bf16)0.0f;
+            __bf16 *row = rows + ((size_t)tile * 64 + mf_row(3 * u + k, h)) * 8, *row1 = row + 32 * 8;
+            const float ev[3] = {e.x, e.y, e.z}, mv[3] = {ml.x, ml.y, ml.z};
+            __bf16 mh[3];
+            for (int i = 0; i < 3; ++i) {
+                const __bf16 eh = (__bf16)ev[i]; mh[i] = (__bf16)mv[i];
+                row[i] = eh; row[3 + i] = mh[i];
+                row1[i] = (__bf16)(ev[i] - (float)eh);                   // the differences are exact in fp32
+                row1[3 + i] = (__bf16)(mv[i] - (float)mh[i]);
+            }
+            row[6] = (__bf16)0.0f; row[7] = mh[0]; row1[6] = mh[1]; row1[7] = mh[2];
         }
     }
     MfGroup G;
@@ -115,7 +130,8 @@ struct MfRay {
     f3 o, d;
     float wd;        // >= |d|
     float wod;       // >= |o| |d|
-    uint32_t dyz, one;   // bf16 pairs (d.y, d.z) and (1, 0)
+    uint32_t dyz, tail;  // bf16 pairs (d_hi.y, d_hi.z) and, by lane half, (1, d_lo.x) or (d_lo.y, d_lo.z)
+    uint32_t dx_hi;      // bf16(d.x) in the upper 16 bits
     bool valid;
 };
 
@@ -126,19 +142,26 @@ __device__ __forceinline__ uint32_t pack_bf16(float lo, float hi)
     return __builtin_bit_cast(uint32_t, p);
 }
 
-// margin(): F := e.(d x o) + m.d in exact arithmetic on the float inputs (identical for world and local origin).
-// (1) bf16 side.  With e~ = bf16(fl(e)), m~' = bf16(fl(v'_a x v'_b)), cv~' = bf16(fl(d x fl(o - c))), d~ = bf16(d), bf16
-//     unit round-off 2^-9, fp32 2^-24, P = |v'_a||v'_b| >= |m'|, products exact and accumulated in fp32:
-//         |F~ - F| <= 2^-7.9 (|e||cv'| + |m'||d|) + 2^-21 (|e||o'| + P)|d|
-//     (first term: bf16 rounding of both factors; second: fp32 rounding of d x (o - c) and of v'_a x v'_b).
+// mf_margin(): F := e.(d x o) + m.d in exact arithmetic on the float inputs (identical for world and local origin).
+// (1) bf16 side.  u = 2^-8 is the bf16 unit round-off (8-bit significand, round to nearest even), x_hi = bf16(x),
+//     x_lo = bf16(x - x_hi) (the difference is exact in fp32), so |x - x_hi| <= u|x| and |x - x_hi - x_lo| <= u^2|x|,
+//     componentwise and hence in norm.  With e = fl(v_a - v_k), m' = fl(v'_a x v'_k), cv' = fl(d x fl(o - c)):
+//         e.cv' - (e_hi + e_lo).cv_hi              = e.(cv' - cv_hi) + (e - e_hi - e_lo).cv_hi   <= (u + u^2(1+u)) |e||cv'|
+//         m'.d - (m_hi + m_lo).d_hi - m_hi.d_lo    = (m' - m_hi - m_lo).d_hi + (m' - m_hi).d_lo + m'.(d - d_hi - d_lo)
+//                                                                                               <= 3 u^2 (1+u) |m'||d|
+//     The 16 products are exact in fp32; their accumulation inside the MFMA is bounded by 2^-17 (|e||cv'| + |m'||d|)
+//     (16 additions, 2^-21 each: 8x the round-to-nearest figure, so truncating adders are covered too).  Together:
+//         |F~ - F_local| <= 2^-8 (1 + 2^-6) |e||cv'| + 2^-14 |m'||d|
+//     where F_local uses the fp32 values above; those differ from the exact local quantities by fp32 rounding of
+//     d x (o - c) and v'_a x v'_k: <= 2^-21 (|e||o'| + P)|d| with P = |v'_a||v'_b| >= |m'|  ("cancel" below, 2^-20).
 // (2) reference side.  The shader accepts edge k iff -A < B with A = dot(fl(e), fl(d x o)), B = dot(fl(v_a x v_b), d)
-//     evaluated in fp32 (:226-245).  |A + B - F| <= 4u|e||d x o| + 3u|e||d||o| + 3u|v_a||v_b||d| + 3u|m||d|, u = 2^-24,
-//     so an accepted edge has F > -(7u E|o||d| + 6u Pw|d|) with Pw >= |v_a||v_b| >= |m|.
-// A triangle the reference accepts therefore has F~_k > -(local + cancel + world) for all three edges with the
-// generous constants below (2^-7 for 2^-7.9, 2^-20 = 16u for 7u / 6u / 2^-21).
+//     evaluated in fp32 (:226-245).  |A + B - F| <= 4w|e||d x o| + 3w|e||d||o| + 3w|v_a||v_b||d| + 3w|m||d|, w = 2^-24,
+//     so an accepted edge has F > -(7w E|o||d| + 6w Pw|d|) with Pw >= |v_a||v_b| >= |m|  ("world" below, 2^-20 = 16w).
+// A triangle the reference accepts therefore has F~_k > -(local + cancel + world) for all three edges.  E, Ml, P, Pw and
+// the per-ray norms are upper bounds (inflated by 1.001 against their own rounding).
 __device__ __forceinline__ float mf_margin(const MfGroup &G, float ncv, float no, const MfRay &r)
 {
-    float local = 0.0078125f * __builtin_fmaf(G.E, ncv, G.Ml * r.wd);                         // 2^-7 (E|cv'| + Ml|d|)
+    float local = __builtin_fmaf(0.00396728515625f * G.E, ncv, 6.103515625e-05f * (G.Ml * r.wd));   // 2^-8 (1 + 2^-6) E|cv'| + 2^-14 Ml|d|
     float cancel = 9.5367431640625e-07f * (__builtin_fmaf(G.E, no, G.P) * r.wd);              // 2^-20 (E|o'| + P)|d|
     float world = 9.5367431640625e-07f * __builtin_fmaf(G.E, r.wod, G.Pw * r.wd);             // 2^-20 (E|o||d| + Pw|d|)
     return (local + cancel) + (world + 1e-30f);
@@ -201,10 +224,9 @@ __global__ void __launch_bounds__(256) intersect_mfma_kernel(SceneView sc, WaveB
     // the vector-memory counter the A-tile prefetch uses
     typedef const float __attribute__((address_space(4))) *ConstFloats;
     const ConstFloats groups_k = (ConstFloats)(uintptr_t)mf.groups;
-    // A tiles: every lane loads 16 bytes per tile from base + a_off + 512 t.  Lanes 0-31 (k = 0..7) walk the tiles, lanes
-    // 32-63 (k = 8..15, unused) keep reading the all-zero padding quad behind the last one: no exec masking, no re-zeroing
+    // A tiles: every lane loads 16 bytes per tile (its row of its K panel) from base + a_off + 1024 t
     const char *A_bytes = reinterpret_cast<const char *>(mf.A);
-    const uint32_t a_inc = half ? 0u : (uint32_t)(kMfQuadTiles * 512);
+    constexpr uint32_t kQuadBytes = kMfQuadTiles * 1024;
 
     for (uint32_t base = blockIdx.x * kRaysPerBlock; base < n_rays; base += gridDim.x * kRaysPerBlock) {
         MfRay ray[S];
@@ -217,8 +239,11 @@ __global__ void __launch_bounds__(256) intersect_mfma_kernel(SceneView sc, WaveB
             if (r.valid) { float4 a = qin.a[slot], b = qin.b[slot]; r.o = mk(a.x, a.y, a.z); r.d = mk(a.w, b.x, b.y); }
             r.wd = __builtin_sqrtf(dot3(r.d, r.d)) * 1.001f;
             r.wod = (__builtin_sqrtf(dot3(r.o, r.o)) * 1.001f) * r.wd;
-            r.dyz = half ? 0u : pack_bf16(r.d.y, r.d.z);
-            r.one = half ? 0u : pack_bf16(1.0f, 0.0f);
+            const uint32_t dxy = pack_bf16(r.d.x, r.d.y);
+            r.dyz = pack_bf16(r.d.y, r.d.z);
+            r.dx_hi = dxy << 16;
+            const f3 dl = mk(r.d.x - __uint_as_float(dxy << 16), r.d.y - __uint_as_float(dxy & 0xffff0000u), r.d.z - __uint_as_float(r.dyz & 0xffff0000u));
+            r.tail = half ? pack_bf16(dl.y, dl.z) : pack_bf16(1.0f, dl.x);
         }
         uint32_t qn = 0, n_total = 0;                            // wave-uniform
         const uint32_t wave_slot0 = base + (uint32_t)(wave * S) * 32u;
@@ -231,12 +256,11 @@ __global__ void __launch_bounds__(256) intersect_mfma_kernel(SceneView sc, WaveB
         // The A tiles of the next quad are fetched while the current one is processed (the loads would otherwise sit
         // right in front of the MFMA that needs them: one exposed L2 round trip per tile).  Two register sets, the quad
         // loop is unrolled by two so that they swap roles without moves.
-        uint32_t a_off = half ? mf.n_quads * (uint32_t)(kMfQuadTiles * 512) + (uint32_t)col * 16u
-                              : q_begin * (uint32_t)(kMfQuadTiles * 512) + (uint32_t)col * 16u;
+        uint32_t a_off = q_begin * kQuadBytes + (uint32_t)half * 512u + (uint32_t)col * 16u;
         auto fetch_quad = [&](uint4 (&dst)[kMfQuadTiles]) {            // fetches the quad a_off points at, then advances
 #pragma unroll
-            for (int t = 0; t < kMfQuadTiles; ++t) dst[t] = *reinterpret_cast<const uint4 *>(A_bytes + a_off + (uint32_t)(t * 512));
-            a_off += a_inc;                                            // the quad after the last one is the zero padding: in bounds
+            for (int t = 0; t < kMfQuadTiles; ++t) dst[t] = *reinterpret_cast<const uint4 *>(A_bytes + a_off + (uint32_t)(t * 1024));
+            a_off += kQuadBytes;                                       // the quad after the last one is the zero padding: in bounds
         };
         bf16x8 B[S];
         float thresh[S];
@@ -257,10 +281,10 @@ __global__ void __launch_bounds__(256) intersect_mfma_kernel(SceneView sc, WaveB
                     // empty slot: nothing survives.  Margin not finite or so large that the bf16 products could overflow
                     // (bounds NaN for non-finite vertices, huge coordinates): NaN threshold, everything survives.
                     thresh[s] = (!r.valid || debug_skip_exact == 2) ? __builtin_inff() : (margin < 1.0e30f ? -margin : __builtin_nanf(""));
-                    uint4 bw;
-                    bw.x = half ? 0u : pack_bf16(cvl.x, cvl.y);
-                    bw.y = half ? 0u : pack_bf16(cvl.z, r.d.x);
-                    bw.z = r.dyz; bw.w = r.one;                                               // k = 8..15 (upper lane half) is zero
+                    uint4 bw;                                                                 // K layout: see MfView
+                    bw.x = pack_bf16(cvl.x, cvl.y);
+                    bw.y = (pack_bf16(cvl.z, 0.0f) & 0xffffu) | r.dx_hi;
+                    bw.z = r.dyz; bw.w = r.tail;
                     B[s] = __builtin_bit_cast(bf16x8, bw);
                 }
             }

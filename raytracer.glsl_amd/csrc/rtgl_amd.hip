@@ -177,7 +177,7 @@ struct rtgl_context {
 
     // bounce-wavefront pipeline buffers
     float2 *d_group_bounds = nullptr;
-    MfGroup *d_mf_groups = nullptr; uint4 *d_mf_A = nullptr; uint32_t *d_mf_order = nullptr; uint32_t n_mf_groups = 0, mf_group_quads = 4;   // bf16 matrix-core broad phase
+    MfGroup *d_mf_groups = nullptr; uint4 *d_mf_A = nullptr; uint32_t *d_mf_order = nullptr; uint32_t n_mf_groups = 0, mf_group_quads = 16;   // bf16 matrix-core broad phase
     void *d_wave = nullptr; size_t wave_capacity = 0; bool wave_multi = false;   // queues (+ per-pixel state when u_samples > 1)
     uint32_t *d_counts = nullptr; uint32_t counts_capacity = 0;
     uint32_t *h_counts = nullptr;            // pinned: ray counts per bounce of the most recent finished frame
@@ -189,7 +189,7 @@ struct rtgl_context {
     bool tris_dirty = false, visits_dirty = false;
     FrameParams params{};
     bool have_params = false;
-    int opt_kernel = RTGL_KERNEL_WAVEFRONT_MFMA, opt_rng_state = 0, opt_counters = 0, opt_kernel_timing = 0, opt_wf_rays = 4, opt_wf_mode = kLds, opt_wf_chunk = 256, opt_wf_early = 0, opt_wf_packed = 0, opt_mf_sets = 2, opt_mf_chunk_quads = 64, opt_mf_group_quads = 4, opt_debug_skip_exact = 0;
+    int opt_kernel = RTGL_KERNEL_WAVEFRONT_MFMA, opt_rng_state = 0, opt_counters = 0, opt_kernel_timing = 0, opt_wf_rays = 4, opt_wf_mode = kLds, opt_wf_chunk = 256, opt_wf_early = 0, opt_wf_packed = 0, opt_mf_sets = 2, opt_mf_chunk_quads = 64, opt_mf_group_quads = 16, opt_debug_skip_exact = 0;
 };
 
 static int fail(rtgl_context *ctx, int code, const std::string &msg)
@@ -453,7 +453,7 @@ static int rebuild_triangles(rtgl_context *ctx)
         HIPCHK(ctx, hipMalloc((void **)&ctx->d_mf_order, order.size() * 4));
         HIPCHK(ctx, hipMemcpyAsync(ctx->d_mf_order, order.data(), order.size() * 4, hipMemcpyHostToDevice, ctx->stream));
         HIPCHK(ctx, hipMalloc((void **)&ctx->d_mf_groups, (size_t)ctx->n_mf_groups * sizeof(MfGroup)));
-        const size_t a_bytes = ((size_t)ctx->n_mf_groups * ctx->mf_group_quads + 1) * kMfQuadTiles * 32 * sizeof(uint4);   // + one zero quad
+        const size_t a_bytes = ((size_t)ctx->n_mf_groups * ctx->mf_group_quads + 1) * kMfQuadTiles * 64 * sizeof(uint4);   // two K panels per tile; + one zero quad
         if (a_bytes > 0xFFFF0000ull) return fail(ctx, RTGL_ERR_INVALID, "mesh too large for the 32-bit tile offsets of the kernel-3 scan");
         HIPCHK(ctx, hipMalloc((void **)&ctx->d_mf_A, a_bytes));
         HIPCHK(ctx, hipMemsetAsync(ctx->d_mf_A, 0, a_bytes, ctx->stream));
@@ -555,7 +555,10 @@ static void launch_intersect_mfma(rtgl_context *ctx, const SceneView &sc, uint32
     uint32_t chunk_quads = ((uint32_t)ctx->opt_mf_chunk_quads + gq - 1) / gq * gq;             // whole groups per chunk
     if (chunk_quads > kMfMaxChunkQuads) chunk_quads = kMfMaxChunkQuads / gq * gq;
     const uint32_t est = estimate_rays(ctx, n0, bounce), rays_per_block = 4u * S * 32u;
-    dim3 grid((est + rays_per_block - 1) / rays_per_block, (n_quads + chunk_quads - 1) / chunk_quads);
+    const uint32_t blocks_x = (est + rays_per_block - 1) / rays_per_block;
+    // late bounces have few rays: split the triangle range finer so that the launch still fills the chip several times over
+    while (chunk_quads > gq && (uint64_t)blocks_x * ((n_quads + chunk_quads - 1) / chunk_quads) < 4096u) chunk_quads = std::max(gq, chunk_quads / 2 / gq * gq);
+    dim3 grid(blocks_x, (n_quads + chunk_quads - 1) / chunk_quads);
     MfView mf{ctx->d_mf_groups, ctx->n_mf_groups, gq, n_quads, ctx->d_mf_A, ctx->d_mf_order};
     if (ctx->opt_counters)
         hipLaunchKernelGGL((intersect_mfma_kernel<S, true>), grid, dim3(256), 0, ctx->stream, sc, ctx->wb, mf, bounce, chunk_quads, ctx->d_counters, ctx->opt_debug_skip_exact);
@@ -872,7 +875,7 @@ extern "C" int rtgl_set_option(rtgl_context *ctx, const char *key, int value)
         if (value < 1 || (uint32_t)value > kMfMaxChunkQuads) return fail(ctx, RTGL_ERR_INVALID, "mf_chunk_quads must be in [1, 128]");
         ctx->opt_mf_chunk_quads = value;
     } else if (!strcmp(key, "mf_group_quads")) {
-        if (value != 1 && value != 2 && value != 4 && value != 8 && value != 16) return fail(ctx, RTGL_ERR_INVALID, "mf_group_quads must be 1, 2, 4, 8 or 16");
+        if (value < 1 || value > (int)kMfMaxGroupQuads || (value & (value - 1))) return fail(ctx, RTGL_ERR_INVALID, "mf_group_quads must be a power of two in [1, 64]");
         if (value != ctx->opt_mf_group_quads) ctx->tris_dirty = true;                          // local origins and A tiles are per group
         ctx->opt_mf_group_quads = value;
     } else if (!strcmp(key, "wf_packed")) {

@@ -8,13 +8,12 @@ python - "$@" <<'PY'
 import json,sys; d=json.load(open('gpurun_out/ab.json')); print(" ".join(sys.argv[1:]), '->', round(d['value'],2),'Mpaths/s', round(d['ms_per_step'],2),'ms', 'avg launch ms', round(d['roofline']['avg_launch_ms'],3), 'cand', d['counters_per_frame']['candidates'])
 PY
 }
-run --kernel 2
-run --kernel 3 --mf-group-quads 1
-run --kernel 3 --mf-group-quads 2
 run --kernel 3 --mf-group-quads 4
 run --kernel 3 --mf-group-quads 8
 run --kernel 3 --mf-group-quads 16
-run --kernel 3 --mf-group-quads 4 --mf-sets 4
-run --kernel 3 --mf-group-quads 8 --mf-sets 4
-run --kernel 3 --mf-group-quads 4 --mf-chunk-quads 32
-run --kernel 3 --mf-group-quads 4 --mf-chunk-quads 128
+run --kernel 3 --mf-group-quads 32
+run --kernel 3 --mf-group-quads 64
+run --kernel 3 --mf-group-quads 16 --mf-sets 4
+run --kernel 3 --mf-group-quads 64 --mf-sets 4
+run --kernel 3 --mf-group-quads 16 --mf-chunk-quads 32
+run --kernel 3 --mf-group-quads 32 --mf-chunk-quads 128
