@@ -131,9 +131,9 @@ int rtgl_read_rng_state(rtgl_context *ctx, uint32_t *xyzw);    /* per local pixe
 /* keys: "kernel" (enum above), "wf_rays" (rays per lane 1/2/4/8), "wf_mode" (0 scalar-fed, 1 LDS tiles),
  * "wf_chunk" (triangles per work item of the split intersect kernel, multiple of 64), "wf_early" (leading bounces
  * that use the wave-level edge short circuit), "wf_packed" (v_pk_fma_f32 ray pairs on/off), "mf_sets" (32-ray sets
- * per wave of the kernel-3 scan: 2 or 4), "mf_chunk_quads" (40-triangle quads per work item), "mf_group_quads" (quads sharing one local origin: a power
- * of two up to 64; changing it rebuilds the broad-phase data at the next frame), "rng_state", "counters",
- * "kernel_timing" */
+ * per wave of the kernel-3 scan: 2), "mf_chunk_quads" (40-triangle quads per work item), "mf_group_quads" (quads
+ * sharing one local origin: a power of two up to 64; changing it rebuilds the broad-phase data at the next frame),
+ * "rng_state", "counters", "kernel_timing" */
 int rtgl_set_option(rtgl_context *ctx, const char *key, int value);
 int rtgl_get_option(rtgl_context *ctx, const char *key, int *value);
 /* elapsed GPU milliseconds of the last rtgl_render_frame (HIP events on the context's stream) */

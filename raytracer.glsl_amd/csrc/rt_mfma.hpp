@@ -59,6 +59,7 @@ struct MfView {
     //   panel 1 (k 8..15, lanes 32-63): e_lo.x e_lo.y e_lo.z  m_lo.x m_lo.y m_lo.z  m_hi.y m_hi.z    x   cv.x cv.y cv.z  d_hi.x d_hi.y d_hi.z  d_lo.y d_lo.z
     // i.e. F~ = (e_hi + e_lo).cv_hi + (m_hi + m_lo).d_hi + m_hi.d_lo  (+ bias, -3e38 on padding rows, 0 otherwise)
     const uint4 *A;
+    uint32_t *dbg_log;       // diagnostics only
     const uint32_t *order;   // storage position -> visit index.  Triangles are stored in Morton order of their centroids
                              // so that the triangles of a group are neighbours (tight local bounds); hits are merged by VISIT
                              // index, so the reference's first-visited-wins tie rule (:349) is unaffected by the reordering
@@ -167,14 +168,14 @@ __device__ __forceinline__ float mf_margin(const MfGroup &G, float ncv, float no
     return (local + cancel) + (world + 1e-30f);
 }
 
-// Exact reference-order test of the queued survivors, 64 per pass with every lane busy.  Kept out of line: it is
-// reached from every unrolled (tile, ray set, triangle) position of the broad-phase loop and inlining it there put
-// ~40 copies of the exact test between the hot instructions.  (A separate narrow-phase kernel fed through a global
-// candidate buffer was also measured: 30 us per bounce on its own, but the extra launch and the buffer traffic made
-// the frame 3% slower than doing it here.)
-// Everything is passed BY VALUE: a reference to a kernel-argument struct would force the kernel to keep that struct in
-// scratch memory and read its fields back from there inside the hot loop (seen: a scratch load + s_waitcnt vmcnt(0) per
-// step, which also waited for the A-tile prefetch).
+// Exact reference-order test of the queued survivors, 64 per pass with every lane busy.  Inlined at exactly three places
+// (once per unrolled loop step, once after the loop): the queue holds a whole step's worst case, so no flush is needed
+// between the tiles of a step.  History: with a small queue the flush sat at every (tile, ray set, triangle) position;
+// inlined there it put ~40 copies of the exact test between the hot instructions, and as an out-of-line function it
+// LOST HITS nondeterministically (a few per 2 M rays; s_swappc callee reading the LDS queue -- flat_load or ds_read alike;
+// the inlined form of the same source never did in any run).  Not understood, so no device function calls in this kernel.
+// (A separate narrow-phase kernel fed through a global candidate buffer was also measured: 30 us per bounce on its own,
+// but the extra launch and the buffer traffic made the frame 3% slower than doing it here.)
 struct MfFlushArgs {
     const float4 *ray_a, *ray_b;
     const TriEdges *tri_edges; const TriPlane *tri_planes;
@@ -182,14 +183,19 @@ struct MfFlushArgs {
     const uint32_t *order;
     uint32_t wave_slot0, v_chunk_begin, v_chunk_end;
     int debug_skip_exact;
+    uint32_t *dbg_log;      // diagnostics (debug_skip_exact = 4): [0] = count, then (slot, storage position) pairs of every queued survivor
 };
 
-__device__ __attribute__((noinline)) void mf_flush(MfFlushArgs f, const uint32_t *queue, uint32_t qn)
+__device__ __forceinline__ void mf_flush(const MfFlushArgs &f, const uint32_t *queue, uint32_t qn)
 {
     for (uint32_t i = threadIdx.x & 63u; i < qn; i += 64u) {
         const uint32_t e = queue[i];
         const uint32_t pos = f.v_chunk_begin + (e & 0xffffu);                 // storage position
-        if (pos < f.v_chunk_end && !f.debug_skip_exact) {
+        if (f.debug_skip_exact == 4 && pos < f.v_chunk_end) {
+            const uint32_t at = atomicAdd(f.dbg_log, 1u);
+            if (at < (1u << 22)) { f.dbg_log[2 + 2 * at] = f.wave_slot0 + (e >> 16); f.dbg_log[3 + 2 * at] = pos; }
+        }
+        if (pos < f.v_chunk_end && (f.debug_skip_exact == 0 || f.debug_skip_exact == 4)) {
             const uint32_t slot = f.wave_slot0 + (e >> 16), v = f.order[pos];
             const float4 a = f.ray_a[slot], b = f.ray_b[slot];
             TriRay tr; tr.o = mk(a.x, a.y, a.z); tr.d = mk(a.w, b.x, b.y); tr.cv = cross3(tr.d, tr.o); tr.ncv = tr.nd = 0.0f;
@@ -199,13 +205,19 @@ __device__ __attribute__((noinline)) void mf_flush(MfFlushArgs f, const uint32_t
     }
 }
 
-template <int S, bool kCount>
+// diagnostics (option debug_skip_exact = 3): every (ray, triangle) pair the broad phase REJECTS also gets the exact test;
+// pairs the exact test accepts are logged -- the log must stay empty, anything in it is a hole in mf_margin()
+struct MfVerifyLog { uint32_t n; uint32_t pad[3]; float ev[64][16]; };
+
+template <int S, bool kCount, bool kVerify = false>
 __global__ void __launch_bounds__(256) intersect_mfma_kernel(SceneView sc, WaveBuffers wb, MfView mf, uint32_t bounce,
                                                              uint32_t chunk_quads, Counters *__restrict__ counters, int debug_skip_exact)
 {
     // grid: x = blocks of 4 waves x S ray sets x 32 rays (grid-stride), y = chunks of `chunk_quads` quads (a multiple of
     // the group size, so a group never straddles two chunks)
-    constexpr uint32_t kQueue = 256;                          // entries per wave: (ray in wave) << 16 | triangle offset in chunk
+    // per-wave survivor queue, entry = (ray in wave) << 16 | triangle offset in chunk.  One loop step (4 tiles x S ray sets x
+    // 5 triangles x 64 lanes) can add at most kStepMax entries, and the queue is drained between steps once it holds kDrain
+    constexpr uint32_t kStepMax = kMfQuadTiles * S * 5 * 64, kDrain = 192, kQueue = kStepMax + kDrain;
     __shared__ uint32_t lds_queue[4 * kQueue];
     const uint32_t n_rays = wb.counts[bounce];
     const RayQueue qin = (bounce & 1u) ? wb.q[1] : wb.q[0];
@@ -219,7 +231,7 @@ __global__ void __launch_bounds__(256) intersect_mfma_kernel(SceneView sc, WaveB
     unsigned long long c_cand_total = 0;
     uint32_t *queue = lds_queue + wave * kQueue;
     const uint32_t n_tri_visits = sc.n_tri_visits;
-    MfFlushArgs fa{qin.a, qin.b, sc.tri_edges, sc.tri_planes, best, mf.order, 0u, v_chunk_begin, v_chunk_end, debug_skip_exact};
+    MfFlushArgs fa{qin.a, qin.b, sc.tri_edges, sc.tri_planes, best, mf.order, 0u, v_chunk_begin, v_chunk_end, debug_skip_exact, mf.dbg_log};
     // group records through the constant address space: uniform index => s_load, which neither waits on nor is held up by
     // the vector-memory counter the A-tile prefetch uses
     typedef const float __attribute__((address_space(4))) *ConstFloats;
@@ -303,6 +315,15 @@ __global__ void __launch_bounds__(256) intersect_mfma_kernel(SceneView sc, WaveB
                     const f32x16 zero = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
                     acc[s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Aop, B[s], zero, 0, 0, 0);
                 }
+                // HAZARD FENCE.  Both accumulators pass through this (empty but for 4 wait states) asm statement, which (a) keeps
+                // them in distinct registers, (b) puts every VALU read of a result behind BOTH matrix instructions and (c) adds
+                // slack to the compiler's exact wait-state count.  Without it the compiler reused one register block:
+                //   mfma v[18:33] ; s_nop ; 5 x v_min3 reading v18..v32 ; mfma v[18:33]   <- issued right behind the last read
+                // and a few times per 10^8 tiles the lanes 16-31 / 48-63 of one tile saw wrong values (spurious or LOST
+                // survivors, i.e. lost hits; run-to-run different).  tools/mfma_hazard_probe.hip reproduces the write-after-read
+                // case in isolation (tens of thousands of wrong lanes with no instruction in between); LLVM's hazard recogniser
+                // does not pad it.  With the fence the survivor set is identical in every run (scripts/dbg_cand.py).
+                asm volatile("s_nop 3" : "+v"(acc[0]), "+v"(acc[S - 1]));
 #pragma unroll
                 for (int s = 0; s < S; ++s) {
 #pragma unroll
@@ -312,6 +333,27 @@ __global__ void __launch_bounds__(256) intersect_mfma_kernel(SceneView sc, WaveB
                     const float mx = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(mn[s][0], mn[s][1]), mn[s][2]), mn[s][3]), mn[s][4]);   // two v_max3
                     any_lane |= !(mx <= thresh[s]);
                 }
+                if (kVerify) {
+                    MfVerifyLog *log = reinterpret_cast<MfVerifyLog *>(reinterpret_cast<char *>(counters) + 64);
+                    for (int s = 0; s < S; ++s)
+                        for (int u = 0; u < 5; ++u) {
+                            const uint32_t pos = v_chunk_begin + (tile - tile_begin) * kMfTileTris + 5u * (uint32_t)half + (uint32_t)u;
+                            if (pos < v_chunk_end && ray[s].valid && mn[s][u] <= thresh[s]) {
+                                const uint32_t v = mf.order[pos];
+                                TriRay tr; tr.o = ray[s].o; tr.d = ray[s].d; tr.cv = cross3(tr.d, tr.o); tr.ncv = tr.nd = 0.0f;
+                                const float t = tri_exact(sc.tri_edges[v], sc.tri_planes[v], tr);
+                                if (kEps < t && t < kInf) {
+                                    const uint32_t at = atomicAdd(&log->n, 1u);
+                                    if (at < 64u) {
+                                        float *e = log->ev[at];
+                                        e[0] = (float)(wave_slot0 + s * 32 + col); e[1] = (float)v; e[2] = (float)pos; e[3] = (float)(q >> group_shift);
+                                        e[4] = acc[s][3 * u]; e[5] = acc[s][3 * u + 1]; e[6] = acc[s][3 * u + 2]; e[7] = thresh[s];
+                                        e[8] = tr.o.x; e[9] = tr.o.y; e[10] = tr.o.z; e[11] = tr.d.x; e[12] = tr.d.y; e[13] = tr.d.z; e[14] = t; e[15] = (float)bounce;
+                                    }
+                                }
+                            }
+                        }
+                }
                 if (__builtin_amdgcn_ballot_w64(any_lane) != 0ull) {
 #pragma unroll
                     for (int s = 0; s < S; ++s)
@@ -319,7 +361,6 @@ __global__ void __launch_bounds__(256) intersect_mfma_kernel(SceneView sc, WaveB
                         for (int u = 0; u < 5; ++u) {
                             const unsigned long long m = __builtin_amdgcn_ballot_w64(!(mn[s][u] <= thresh[s]));
                             if (m) {                                                        // wave-uniform
-                                if (qn > kQueue - 64u) flush();
                                 if ((m >> lane) & 1ull) {
                                     const uint32_t v_off = (tile - tile_begin) * kMfTileTris + 5u * (uint32_t)half + (uint32_t)u;
                                     queue[qn + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = ((uint32_t)(s * 32 + col) << 16) | v_off;
@@ -334,7 +375,11 @@ __global__ void __launch_bounds__(256) intersect_mfma_kernel(SceneView sc, WaveB
         fetch_quad(a0);
         for (uint32_t q = q_begin; q < q_end; q += 2u) {
             step(q, a0, a1);
-            if (q + 1u < q_end) step(q + 1u, a1, a0);
+            if (qn >= kDrain) flush();
+            if (q + 1u < q_end) {
+                step(q + 1u, a1, a0);
+                if (qn >= kDrain) flush();
+            }
         }
         flush();
         const uint32_t n_cand = (lane == 0) ? n_total : 0u;

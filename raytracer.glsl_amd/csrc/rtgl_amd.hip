@@ -177,7 +177,7 @@ struct rtgl_context {
 
     // bounce-wavefront pipeline buffers
     float2 *d_group_bounds = nullptr;
-    MfGroup *d_mf_groups = nullptr; uint4 *d_mf_A = nullptr; uint32_t *d_mf_order = nullptr; uint32_t n_mf_groups = 0, mf_group_quads = 16;   // bf16 matrix-core broad phase
+    MfGroup *d_mf_groups = nullptr; uint4 *d_mf_A = nullptr; uint32_t *d_mf_order = nullptr; uint32_t n_mf_groups = 0, mf_group_quads = 16; uint32_t *d_dbg_log = nullptr;   // bf16 matrix-core broad phase
     void *d_wave = nullptr; size_t wave_capacity = 0; bool wave_multi = false;   // queues (+ per-pixel state when u_samples > 1)
     uint32_t *d_counts = nullptr; uint32_t counts_capacity = 0;
     uint32_t *h_counts = nullptr;            // pinned: ray counts per bounce of the most recent finished frame
@@ -244,8 +244,8 @@ extern "C" int rtgl_create_tiled(rtgl_context **out, int width, int height, int 
     CCHK(hipMalloc((void **)&ctx->d_image_own, img_bytes));
     CCHK(hipMemsetAsync(ctx->d_image_own, 0, img_bytes, ctx->stream));
     ctx->d_image = ctx->d_image_own;
-    CCHK(hipMalloc((void **)&ctx->d_counters, sizeof(Counters)));
-    CCHK(hipMemsetAsync(ctx->d_counters, 0, sizeof(Counters), ctx->stream));
+    CCHK(hipMalloc((void **)&ctx->d_counters, 64 + sizeof(MfVerifyLog)));      // counters, then the kernel-3 verification log
+    CCHK(hipMemsetAsync(ctx->d_counters, 0, 64 + sizeof(MfVerifyLog), ctx->stream));
     CCHK(hipStreamSynchronize(ctx->stream));
 #undef CCHK
     *out = ctx;
@@ -559,8 +559,14 @@ static void launch_intersect_mfma(rtgl_context *ctx, const SceneView &sc, uint32
     // late bounces have few rays: split the triangle range finer so that the launch still fills the chip several times over
     while (chunk_quads > gq && (uint64_t)blocks_x * ((n_quads + chunk_quads - 1) / chunk_quads) < 4096u) chunk_quads = std::max(gq, chunk_quads / 2 / gq * gq);
     dim3 grid(blocks_x, (n_quads + chunk_quads - 1) / chunk_quads);
-    MfView mf{ctx->d_mf_groups, ctx->n_mf_groups, gq, n_quads, ctx->d_mf_A, ctx->d_mf_order};
-    if (ctx->opt_counters)
+    if (ctx->opt_debug_skip_exact == 4 && !ctx->d_dbg_log) {
+        (void)hipMalloc((void **)&ctx->d_dbg_log, (size_t)(2 + (2u << 22)) * 4);
+        (void)hipMemsetAsync(ctx->d_dbg_log, 0, 8, ctx->stream);
+    }
+    MfView mf{ctx->d_mf_groups, ctx->n_mf_groups, gq, n_quads, ctx->d_mf_A, ctx->d_dbg_log, ctx->d_mf_order};
+    if (ctx->opt_debug_skip_exact == 3)
+        hipLaunchKernelGGL((intersect_mfma_kernel<2, true, true>), dim3((est + 255) / 256, grid.y), dim3(256), 0, ctx->stream, sc, ctx->wb, mf, bounce, chunk_quads, ctx->d_counters, 0);
+    else if (ctx->opt_counters)
         hipLaunchKernelGGL((intersect_mfma_kernel<S, true>), grid, dim3(256), 0, ctx->stream, sc, ctx->wb, mf, bounce, chunk_quads, ctx->d_counters, ctx->opt_debug_skip_exact);
     else
         hipLaunchKernelGGL((intersect_mfma_kernel<S, false>), grid, dim3(256), 0, ctx->stream, sc, ctx->wb, mf, bounce, chunk_quads, ctx->d_counters, ctx->opt_debug_skip_exact);
@@ -584,7 +590,7 @@ static int launch_wavefront(rtgl_context *ctx, const SceneView &sc, const FrameP
             if (ctx->opt_kernel == RTGL_KERNEL_WAVEFRONT_SPLIT || ctx->opt_kernel == RTGL_KERNEL_WAVEFRONT_MFMA) {
                 if (sc.n_tri_visits > 0 && ctx->opt_kernel == RTGL_KERNEL_WAVEFRONT_MFMA) {
                     kev_mark(ctx);
-                    if (ctx->opt_mf_sets == 2) launch_intersect_mfma<2>(ctx, sc, n0, b); else launch_intersect_mfma<4>(ctx, sc, n0, b);
+                    launch_intersect_mfma<2>(ctx, sc, n0, b);
                     kev_mark(ctx);
                 } else if (sc.n_tri_visits > 0) {
                     kev_mark(ctx);
@@ -839,6 +845,23 @@ extern "C" int rtgl_get_counters(rtgl_context *ctx, rtgl_counters *out)
     memset(out, 0, sizeof *out);
     out->paths = c.paths; out->segments = c.segments; out->triangle_tests = c.tri_tests;
     out->candidates = c.candidates; out->env_lookups = c.env_lookups;
+    if (ctx->opt_debug_skip_exact == 4 && ctx->d_dbg_log && getenv("RTGL_DEBUG_DUMP")) {      // survivor log -> file, then reset
+        std::vector<uint32_t> h(2 + (2u << 22));
+        HIPCHK(ctx, hipMemcpy(h.data(), ctx->d_dbg_log, h.size() * 4, hipMemcpyDeviceToHost));
+        if (FILE *f = fopen(getenv("RTGL_DEBUG_DUMP"), "ab")) { const uint32_t n = std::min(h[0], 1u << 22); fwrite(&n, 4, 1, f); fwrite(h.data() + 2, 8, n, f); fclose(f); }
+        HIPCHK(ctx, hipMemset(ctx->d_dbg_log, 0, 8));
+    }
+    if (ctx->opt_debug_skip_exact == 3) {          // kernel-3 verification log: pairs the broad phase rejected but the exact test accepts
+        static MfVerifyLog log;
+        HIPCHK(ctx, hipMemcpy(&log, reinterpret_cast<char *>(ctx->d_counters) + 64, sizeof log, hipMemcpyDeviceToHost));
+        fprintf(stderr, "rtgl verify: %u false rejections\n", log.n);
+        for (uint32_t i = 0; i < std::min(log.n, 64u); ++i) {
+            const float *e = log.ev[i];
+            fprintf(stderr, "  slot %.0f visit %.0f pos %.0f group %.0f bounce %.0f  F~ %.9g %.9g %.9g  thresh %.9g  o %.9g %.9g %.9g  d %.9g %.9g %.9g  t %.9g\n",
+                    e[0], e[1], e[2], e[3], e[15], e[4], e[5], e[6], e[7], e[8], e[9], e[10], e[11], e[12], e[13], e[14]);
+        }
+        out->reserved[0] = log.n;
+    }
     return RTGL_OK;
 }
 
@@ -869,7 +892,7 @@ extern "C" int rtgl_set_option(rtgl_context *ctx, const char *key, int value)
     } else if (!strcmp(key, "debug_skip_exact")) {      // timing diagnostics only: the image is wrong
         ctx->opt_debug_skip_exact = value;               // 1: no exact narrow phase; 2: broad phase rejects everything
     } else if (!strcmp(key, "mf_sets")) {
-        if (value != 2 && value != 4) return fail(ctx, RTGL_ERR_INVALID, "mf_sets must be 2 or 4");
+        if (value != 2) return fail(ctx, RTGL_ERR_INVALID, "mf_sets must be 2 (4 sets per wave were measured 10% slower and removed)");
         ctx->opt_mf_sets = value;
     } else if (!strcmp(key, "mf_chunk_quads")) {
         if (value < 1 || (uint32_t)value > kMfMaxChunkQuads) return fail(ctx, RTGL_ERR_INVALID, "mf_chunk_quads must be in [1, 128]");

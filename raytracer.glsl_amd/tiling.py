@@ -55,7 +55,11 @@ class FrameGatherer:
         self.pad = padded_rows(height, world, strip_rows)
         self.local = torch.zeros((self.pad, width, 4), dtype=torch.float32, device=device)
         self.n_local = len(strip_rows_of(height, rank, world, strip_rows))
-        if rank == 0:
+        if world == 1:
+            # a single rank owns every row in image order: the local buffer IS the assembled image, nothing to exchange or copy
+            self.gathered = self.perm = None
+            self.full = self.local[:height]
+        elif rank == 0:
             self.gathered = torch.zeros((world, self.pad, width, 4), dtype=torch.float32, device=device)
             self.perm = torch.from_numpy(row_permutation(height, world, strip_rows)).to(device)
             self.full = torch.zeros((height, width, 4), dtype=torch.float32, device=device)
@@ -66,7 +70,6 @@ class FrameGatherer:
         """One exchange step.  Returns the assembled (height, width, 4) image on rank 0, None elsewhere."""
         torch = self.torch
         if self.world == 1:
-            self.full.copy_(self.local[: self.height])
             return self.full
         import torch.distributed as dist
         if self.rank == 0:

@@ -13,7 +13,5 @@ run --kernel 3 --mf-group-quads 8
 run --kernel 3 --mf-group-quads 16
 run --kernel 3 --mf-group-quads 32
 run --kernel 3 --mf-group-quads 64
-run --kernel 3 --mf-group-quads 16 --mf-sets 4
-run --kernel 3 --mf-group-quads 64 --mf-sets 4
 run --kernel 3 --mf-group-quads 16 --mf-chunk-quads 32
 run --kernel 3 --mf-group-quads 32 --mf-chunk-quads 128
