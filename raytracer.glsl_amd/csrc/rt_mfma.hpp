@@ -44,7 +44,7 @@ struct alignas(16) MfGroup {
     float cx, cy, cz;   // local origin (centre of the group's bounding box)
     float E;            // >= max |e_k|
     float Ml;           // >= max |m'_k|                        (local moments)
-    float Pw;           // >= max |v_a| |v_b| >= max |m_k|      (bounds the fp32 rounding of the reference's own cross(v_a, v_b))
+    float Pw;           // >= max |v_a| |v_b| + E |c|           (fp32 rounding of the reference's own cross(v_a, v_b); origin shift with rounded e)
     float P;            // >= max |v'_a| |v'_b|                 (bounds the fp32 rounding of the local cross products)
     float pad1;
 };
@@ -121,6 +121,9 @@ __global__ void __launch_bounds__(64) prepare_mfma_kernel(const float4 *__restri
     MfGroup G;
     G.cx = c.x; G.cy = c.y; G.cz = c.z;
     const float nanv = __builtin_nanf("");
+    // Moving the origin to c is exact only for e = v_a - v_k; with the rounded e the two forms of F differ by
+    // d.((e_exact - e) x c) <= 2^-24 |e||c||d|: folded into Pw (the 2^-20 "world" term of mf_margin)
+    Pw = Pw + E * __builtin_sqrtf(dot3(c, c));
     G.E = bad ? nanv : E * 1.001f; G.Ml = bad ? nanv : Ml * 1.001f; G.Pw = bad ? nanv : Pw * 1.001f;   // NaN bounds: nothing is ever rejected
     G.P = bad ? nanv : P * 1.001f; G.pad1 = 0.0f;
     groups[g] = G;
@@ -168,9 +171,9 @@ __device__ __forceinline__ float mf_margin(const MfGroup &G, float ncv, float no
     return (local + cancel) + (world + 1e-30f);
 }
 
-// Exact reference-order test of the queued survivors, 64 per pass with every lane busy.  Inlined at exactly three places
-// (once per unrolled loop step, once after the loop): the queue holds a whole step's worst case, so no flush is needed
-// between the tiles of a step.  History: with a small queue the flush sat at every (tile, ray set, triangle) position;
+// Exact reference-order test of the queued survivors, 64 per pass with every lane busy.  Inlined at exactly five places
+// (twice per unrolled loop step, once after the loop): the queue holds half a step's worst case, so no flush is needed
+// between the two tiles of a half step.  History: with a small queue the flush sat at every (tile, ray set, triangle) position;
 // inlined there it put ~40 copies of the exact test between the hot instructions, and as an out-of-line function it
 // LOST HITS nondeterministically (a few per 2 M rays; s_swappc callee reading the LDS queue -- flat_load or ds_read alike;
 // the inlined form of the same source never did in any run).  Not understood, so no device function calls in this kernel.
@@ -209,15 +212,18 @@ __device__ __forceinline__ void mf_flush(const MfFlushArgs &f, const uint32_t *q
 // pairs the exact test accepts are logged -- the log must stay empty, anything in it is a hole in mf_margin()
 struct MfVerifyLog { uint32_t n; uint32_t pad[3]; float ev[64][16]; };
 
+#ifndef MF_MIN_BLOCKS
+#define MF_MIN_BLOCKS 4      // waves per SIMD the register allocator must allow: 128 VGPRs (16 spilled in the cold paths), measured +2% over 3 waves
+#endif
 template <int S, bool kCount, bool kVerify = false>
-__global__ void __launch_bounds__(256) intersect_mfma_kernel(SceneView sc, WaveBuffers wb, MfView mf, uint32_t bounce,
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MF_MIN_BLOCKS))) intersect_mfma_kernel(SceneView sc, WaveBuffers wb, MfView mf, uint32_t bounce,
                                                              uint32_t chunk_quads, Counters *__restrict__ counters, int debug_skip_exact)
 {
     // grid: x = blocks of 4 waves x S ray sets x 32 rays (grid-stride), y = chunks of `chunk_quads` quads (a multiple of
     // the group size, so a group never straddles two chunks)
-    // per-wave survivor queue, entry = (ray in wave) << 16 | triangle offset in chunk.  One loop step (4 tiles x S ray sets x
-    // 5 triangles x 64 lanes) can add at most kStepMax entries, and the queue is drained between steps once it holds kDrain
-    constexpr uint32_t kStepMax = kMfQuadTiles * S * 5 * 64, kDrain = 192, kQueue = kStepMax + kDrain;
+    // per-wave survivor queue, entry = (ray in wave) << 16 | triangle offset in chunk.  Half a loop step (2 tiles x S ray sets
+    // x 5 triangles x 64 lanes) can add at most kStepMax entries, and the queue is drained between half steps once it holds kDrain
+    constexpr uint32_t kStepMax = (kMfQuadTiles / 2) * S * 5 * 64, kDrain = 192, kQueue = kStepMax + kDrain;
     __shared__ uint32_t lds_queue[4 * kQueue];
     const uint32_t n_rays = wb.counts[bounce];
     const RayQueue qin = (bounce & 1u) ? wb.q[1] : wb.q[0];
@@ -304,6 +310,7 @@ __global__ void __launch_bounds__(256) intersect_mfma_kernel(SceneView sc, WaveB
             for (int t = 0; t < kMfQuadTiles; ++t) {
                 const uint32_t tile = q * kMfQuadTiles + t;
                 if (tile * kMfTileTris >= n_tri_visits) break;                           // wave-uniform
+                if (t == kMfQuadTiles / 2 && qn >= kDrain) flush();
                 const bf16x8 Aop = __builtin_bit_cast(bf16x8, a_cur[t]);
                 // all S products first (back to back on the matrix pipe), then five v_min3 per ray set and lane, and ONE
                 // compare on the max of the minima: the common "nothing survived" case costs 8 VALU + 1 branch per MFMA
