@@ -327,9 +327,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MF_MIN
                 // slack to the compiler's exact wait-state count.  Without it the compiler reused one register block:
                 //   mfma v[18:33] ; s_nop ; 5 x v_min3 reading v18..v32 ; mfma v[18:33]   <- issued right behind the last read
                 // and a few times per 10^8 tiles the lanes 16-31 / 48-63 of one tile saw wrong values (spurious or LOST
-                // survivors, i.e. lost hits; run-to-run different).  tools/mfma_hazard_probe.hip reproduces the write-after-read
-                // case in isolation (tens of thousands of wrong lanes with no instruction in between); LLVM's hazard recogniser
-                // does not pad it.  With the fence the survivor set is identical in every run (scripts/dbg_cand.py).
+                // survivors, i.e. lost hits; run-to-run different).  The mechanism is not established; every
+                // variant with the reads behind both matrix instructions was clean, every variant without was not.  With the
+                // fence the survivor set is identical in every run (scripts/dbg_cand.py, scripts/dbg_soak.py).
                 asm volatile("s_nop 3" : "+v"(acc[0]), "+v"(acc[S - 1]));
 #pragma unroll
                 for (int s = 0; s < S; ++s) {

@@ -2,11 +2,16 @@
 // result registers?  One asm block: pre-fill the 16 result registers with a marker, issue the MFMA (result = known dot
 // products, never the marker), s_nop N, then copy result register 15 (written last) and register 0.  A lane that still
 // sees the marker read too early.  Run with 1..4 waves per SIMD (the matrix pipe is shared between co-resident waves).
+// (A third series -- VALU reads of the result registers directly followed by the next MFMA that overwrites them, the
+// pattern rt_mfma.hpp had when it lost hits -- was tried here too: the identical asm block produced tens of thousands of
+// wrong lanes in one build of this file and none in another whose surrounding C++ differed, so it proves nothing and was
+// removed.  The scan's fix is validated on the scan itself: scripts/dbg_cand.py, scripts/dbg_soak.py, the regression test.)
 // Second series: NV independent VALU instructions + s_nop, the mix the compiler's hazard recognizer produces when it counts
 // every VALU instruction in between as one wait state ("v_max3, v_max3, v_cmp, s_nop 8" = 12 by its count).
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>
+#include <cstring>
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 template <int N>
@@ -78,52 +83,6 @@ template <int NV, int N> static void run_valu(uint32_t *d, int cus)
     }
 }
 
-// Third series (the one that bit rt_mfma.hpp): VALU READS of an MFMA's destination registers followed by the NEXT MFMA
-// that overwrites those registers (write-after-read).  Registers hold 16 everywhere; v_min3 reads three of them; an MFMA
-// whose results are 64 is issued GAP instructions later.  A lane whose v_min3 result is not 16 saw the overwrite (or the
-// accumulator clear of "srcC = 0") before it had read its operands.
-template <int GAP>
-__global__ void __launch_bounds__(1024) probe_war(uint32_t *bad_lanes, int iters)
-{
-    bf16x8 a, b, a2;
-    for (int i = 0; i < 8; ++i) { a[i] = (__bf16)1.0f; b[i] = (__bf16)1.0f; a2[i] = (__bf16)4.0f; }
-    uint32_t bad = 0;
-    for (int it = 0; it < iters; ++it) {
-        float m0, m1, m2, m3, m4;
-        asm volatile(
-            "v_mfma_f32_32x32x16_bf16 v[32:47], %5, %6, 0\n\t"
-            "s_nop 15\n\ts_nop 15\n\t"
-            "v_min3_f32 %0, v32, v33, v34\n\t"
-            "v_min3_f32 %1, v35, v36, v37\n\t"
-            "v_min3_f32 %2, v38, v39, v40\n\t"
-            "v_min3_f32 %3, v41, v42, v43\n\t"
-            "v_min3_f32 %4, v44, v45, v46\n\t"
-            ".rept %8\n\ts_nop 0\n\t.endr\n\t"
-            "v_mfma_f32_32x32x16_bf16 v[32:47], %7, %6, 0\n\t"
-            "s_nop 15\n\ts_nop 15\n\t"
-            : "=&v"(m0), "=&v"(m1), "=&v"(m2), "=&v"(m3), "=&v"(m4) : "v"(a), "v"(b), "v"(a2), "n"(GAP)
-            : "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47");
-        if (m0 != 16.0f) bad |= 1u;
-        if (m1 != 16.0f) bad |= 2u;
-        if (m2 != 16.0f) bad |= 4u;
-        if (m3 != 16.0f) bad |= 8u;
-        if (m4 != 16.0f) bad |= 16u;
-    }
-    if (bad) atomicOr(&bad_lanes[(threadIdx.x & 63) >> 4], bad);
-    if (bad) atomicAdd(&bad_lanes[4], 1u);
-}
-
-template <int GAP> static void run_war(uint32_t *d, int cus)
-{
-    for (int wps = 1; wps <= 4; ++wps) {
-        (void)hipMemset(d, 0, 32);
-        hipLaunchKernelGGL(probe_war<GAP>, dim3(cus), dim3(256 * wps), 0, 0, d, 200000);
-        uint32_t h[8]; (void)hipMemcpy(h, d, 32, hipMemcpyDeviceToHost);
-        printf("WAR: 5 x v_min3 reading v[32:46], %d x s_nop 0, MFMA overwriting v[32:47]  waves/SIMD %d: lanes with a wrong minimum %u  quarters [%x %x %x %x] (bit i: i-th v_min3)\n",
-               GAP, wps, h[4], h[0], h[1], h[2], h[3]);
-    }
-}
-
 template <int N> static void run(uint32_t *d, int cus)
 {
     for (int wps = 1; wps <= 4; ++wps) {
@@ -142,7 +101,6 @@ int main()
     const int cus = prop.multiProcessorCount;
     run<9>(d, cus); run<10>(d, cus); run<11>(d, cus); run<12>(d, cus);
     run_valu<3, 8>(d, cus); run_valu<6, 5>(d, cus); run_valu<11, 0>(d, cus); run_valu<3, 9>(d, cus); run_valu<3, 10>(d, cus); run_valu<3, 11>(d, cus);
-    run_war<0>(d, cus); run_war<1>(d, cus); run_war<2>(d, cus); run_war<4>(d, cus);
     run_valu<6, 8>(d, cus); run_valu<6, 11>(d, cus); run_valu<12, 5>(d, cus); run_valu<12, 11>(d, cus);
     return 0;
 }
