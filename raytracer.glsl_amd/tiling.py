@@ -48,14 +48,18 @@ class FrameGatherer:
     local buffers are torch tensors of shape (padded_rows, width, 4) float32 living on the device
     the process renders on (CPU tensors with the gloo backend in tests)."""
 
-    def __init__(self, width: int, height: int, rank: int, world: int, device, strip_rows: int = DEFAULT_STRIP_ROWS):
+    def __init__(self, width: int, height: int, rank: int, world: int, device, strip_rows: int = DEFAULT_STRIP_ROWS,
+                 force_collective: bool = False):
+        """force_collective: take the gather + un-permute path even for a single rank (a one-rank process group must be
+        initialised).  Exists so that the RCCL calls of the multi-GPU path can be exercised on a one-GPU box."""
         import torch
         self.torch = torch
         self.width, self.height, self.rank, self.world, self.strip_rows = width, height, rank, world, strip_rows
+        self.collective = world > 1 or force_collective
         self.pad = padded_rows(height, world, strip_rows)
         self.local = torch.zeros((self.pad, width, 4), dtype=torch.float32, device=device)
         self.n_local = len(strip_rows_of(height, rank, world, strip_rows))
-        if world == 1:
+        if not self.collective:
             # a single rank owns every row in image order: the local buffer IS the assembled image, nothing to exchange or copy
             self.gathered = self.perm = None
             self.full = self.local[:height]
@@ -69,7 +73,7 @@ class FrameGatherer:
     def gather(self):
         """One exchange step.  Returns the assembled (height, width, 4) image on rank 0, None elsewhere."""
         torch = self.torch
-        if self.world == 1:
+        if not self.collective:
             return self.full
         import torch.distributed as dist
         if self.rank == 0:

@@ -46,3 +46,55 @@ def test_render_into_torch_tensor_on_torch_stream(rt):
     ctx.bind_device_image(0)
     ctx.set_stream(0)
     ctx.close()
+
+
+def _one_rank_rccl_worker(port, out_path):
+    """Everything bench.py does with torch.distributed for N > 1 -- nccl (= RCCL) process group bound to the device, barrier,
+    gather of the tile buffer into rank 0's list, index_select un-permute, all_reduce of the timing scalar -- on a group of ONE rank."""
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+    import raytracer_glsl_amd as rt
+    import golden_cases as gc2
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    sc = rt.scenes
+    W, H = 200, 120
+    ctx = rt.host.Context(W, H, device=0, rank=0, world=1, strip_rows=16)
+    ctx.upload_scene(sc.scene_mesh(30, 12, env_size=16))
+    gat = rt.tiling.FrameGatherer(W, H, 0, 1, dev, 16, force_collective=True)
+    ctx.bind_device_image(gat.local.data_ptr())
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    dist.barrier(); torch.cuda.synchronize()
+    full = None
+    for p in gc2.frame_sequence(sc, sc.params_c2(), 3):
+        ctx.render(p, sync=False)
+        full = gat.gather()
+    dist.barrier(); torch.cuda.synchronize()
+    tt = torch.tensor([1.5], dtype=torch.float64, device=dev)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    assert float(tt.item()) == 1.5
+    np.save(out_path, full.cpu().numpy())
+    ctx.bind_device_image(0); ctx.set_stream(0); ctx.close()
+    dist.destroy_process_group()
+
+
+def test_rccl_gather_path_on_a_one_rank_group(tmp_path, rt):
+    import os
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "full.npy")
+    ctxm = mp.get_context("spawn")
+    proc = ctxm.Process(target=_one_rank_rccl_worker, args=(29700 + os.getpid() % 2000, out))
+    proc.start(); proc.join(300)
+    assert proc.exitcode == 0
+    sc = rt.scenes
+    ref = rt.host.Context(200, 120)
+    ref.upload_scene(sc.scene_mesh(30, 12, env_size=16))
+    for p in gc.frame_sequence(sc, sc.params_c2(), 3):
+        ref.render(p)
+    want = ref.read_image(); ref.close()
+    assert (np.load(out).view(np.uint32) == want.view(np.uint32)).all()
