@@ -135,7 +135,7 @@ def main():
 
     def step(p):
         ctx.render(p, sync=False)
-        gat.gather()
+        gat.gather(overlap=world > 1)      # N > 1: snapshot + asynchronous RCCL gather, overlapped with the next frame's render
 
     def barrier():
         if world > 1:
@@ -144,6 +144,7 @@ def main():
 
     for _ in range(args.warmup):
         step(next_params())
+    gat.finish()
     timed = [next_params() for _ in range(args.steps)]
     barrier()
     ctx.timing_reset()
@@ -152,6 +153,7 @@ def main():
         step(p)
         if args.sync_each_frame:
             ctx.synchronize()
+    gat.finish()                           # the last frame's exchange and un-permute belong to the timed region
     barrier()
     dt = time.perf_counter() - t0
     if args.no_kernel_timing:
@@ -220,7 +222,7 @@ def main():
             "config": {"workload": f"{args.config}: {W}x{H}, {base.max_bounce} bounces, {scene.n_triangles} triangles + "
                                    f"{scene.spheres.shape[0]} spheres, cube map {scene.env.shape[1] if scene.env is not None else 0}^2, "
                                    f"1 spp/frame progressive, dof={base.use_dof}",
-                       "parallelism": f"{world} GPU(s), {args.strip_rows}-row strips interleaved, gather to rank 0 every frame",
+                       "parallelism": f"{world} GPU(s), {args.strip_rows}-row strips interleaved, gather to rank 0 every frame" + (" (asynchronous, overlapped with the next frame)" if world > 1 else ""),
                        "kernel": ctx.get_option("kernel"), "wf_rays": ctx.get_option("wf_rays"), "wf_mode": ctx.get_option("wf_mode"), "wf_chunk": ctx.get_option("wf_chunk"), "wf_early": ctx.get_option("wf_early"), "wf_packed": ctx.get_option("wf_packed"),
                        "mf_sets": ctx.get_option("mf_sets"), "mf_group_quads": ctx.get_option("mf_group_quads"), "mf_chunk_quads": ctx.get_option("mf_chunk_quads")},
             "roofline": {"bound": "hbm", "achieved": bytes_per_launch / avg_launch_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -56,6 +56,7 @@ class FrameGatherer:
         self.torch = torch
         self.width, self.height, self.rank, self.world, self.strip_rows = width, height, rank, world, strip_rows
         self.collective = world > 1 or force_collective
+        self.send = self.pending = None
         self.pad = padded_rows(height, world, strip_rows)
         self.local = torch.zeros((self.pad, width, 4), dtype=torch.float32, device=device)
         self.n_local = len(strip_rows_of(height, rank, world, strip_rows))
@@ -70,15 +71,44 @@ class FrameGatherer:
         else:
             self.gathered = self.perm = self.full = None
 
-    def gather(self):
-        """One exchange step.  Returns the assembled (height, width, 4) image on rank 0, None elsewhere."""
+    def gather(self, overlap: bool = False):
+        """One exchange step.  Returns the assembled (height, width, 4) image on rank 0, None elsewhere.
+
+        overlap=False: the exchange of THIS frame completes (stream-ordered) before anything enqueued afterwards runs.
+        overlap=True: the tile buffer is snapshotted (one device copy) and gathered asynchronously while the caller renders
+        the next frame into `local`; the image returned on rank 0 is the one completed by the PREVIOUS call (None the first
+        time) -- a display one frame late, the usual trade of a progressive renderer.  Call finish() after the last frame."""
         torch = self.torch
         if not self.collective:
             return self.full
         import torch.distributed as dist
+        if overlap:
+            had = self._complete()
+            if self.send is None:
+                self.send = torch.empty_like(self.local)
+            self.send.copy_(self.local)                              # snapshot on the current stream
+            self.pending = dist.gather(self.send, gather_list=list(self.gathered.unbind(0)) if self.rank == 0 else None, dst=0, async_op=True)
+            return self.full if (self.rank == 0 and had) else None
+        self._complete()
         if self.rank == 0:
             dist.gather(self.local, gather_list=list(self.gathered.unbind(0)), dst=0)
             torch.index_select(self.gathered.view(self.world * self.pad, self.width, 4), 0, self.perm, out=self.full)
             return self.full
         dist.gather(self.local, gather_list=None, dst=0)
         return None
+
+    def _complete(self) -> bool:
+        """Finish the exchange started by the last gather(overlap=True): wait (stream-ordered for RCCL, blocking for gloo),
+        then un-permute on rank 0."""
+        if self.pending is None:
+            return False
+        self.pending.wait()
+        self.pending = None
+        if self.rank == 0:
+            self.torch.index_select(self.gathered.view(self.world * self.pad, self.width, 4), 0, self.perm, out=self.full)
+        return True
+
+    def finish(self):
+        """Completes an overlapped exchange; returns the assembled image of the last frame on rank 0."""
+        self._complete()
+        return self.full if (not self.collective or self.rank == 0) else None

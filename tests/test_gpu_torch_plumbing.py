@@ -71,9 +71,13 @@ def _one_rank_rccl_worker(port, out_path):
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     dist.barrier(); torch.cuda.synchronize()
     full = None
-    for p in gc2.frame_sequence(sc, sc.params_c2(), 3):
+    frames = gc2.frame_sequence(sc, sc.params_c2(), 4)
+    ctx.render(frames[0], sync=False)
+    full = gat.gather()                          # synchronous exchange
+    for p in frames[1:]:
         ctx.render(p, sync=False)
-        full = gat.gather()
+        gat.gather(overlap=True)                 # snapshot + async gather, next frame renders meanwhile (as bench.py does for N > 1)
+    full = gat.finish()
     dist.barrier(); torch.cuda.synchronize()
     tt = torch.tensor([1.5], dtype=torch.float64, device=dev)
     dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -94,7 +98,7 @@ def test_rccl_gather_path_on_a_one_rank_group(tmp_path, rt):
     sc = rt.scenes
     ref = rt.host.Context(200, 120)
     ref.upload_scene(sc.scene_mesh(30, 12, env_size=16))
-    for p in gc.frame_sequence(sc, sc.params_c2(), 3):
+    for p in gc.frame_sequence(sc, sc.params_c2(), 4):
         ref.render(p)
     want = ref.read_image(); ref.close()
     assert (np.load(out).view(np.uint32) == want.view(np.uint32)).all()

@@ -6,6 +6,7 @@ import os
 import sys
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -13,7 +14,7 @@ import torch.multiprocessing as mp
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, port, W, H, strip, frames, out_path):
+def _worker(rank, world, port, W, H, strip, frames, out_path, overlap=False):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -36,19 +37,22 @@ def _worker(rank, world, port, W, H, strip, frames, out_path):
             if y1 > g0:
                 orc.render(scene, p, full, rect=(0, g0, W // 8 * 8, y1), threads=1)
         gat.local[: len(rows)] = torch.from_numpy(full[rows])        # compact local tile buffer
-        result = gat.gather()                                         # the one exchange step per frame
+        result = gat.gather(overlap=overlap)                          # the one exchange step per frame
+    if overlap:
+        result = gat.finish()                                         # overlapped: the last frame's image arrives here
     if rank == 0:
         np.save(out_path, result.numpy())
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_two_rank_tiled_render_equals_single(tmp_path, rt, oracle):
+@pytest.mark.parametrize("overlap", [False, True])
+def test_two_rank_tiled_render_equals_single(tmp_path, rt, oracle, overlap):
     import golden_cases as gc
-    W, H, strip, frames, world = 72, 53, 8, 2, 2
+    W, H, strip, frames, world = 72, 53, 8, 3 if overlap else 2, 2
     out = str(tmp_path / "gathered.npy")
-    port = 29500 + (os.getpid() % 2000)
-    mp.spawn(_worker, args=(world, port, W, H, strip, frames, out), nprocs=world, join=True)
+    port = 29500 + (os.getpid() % 2000) + (17 if overlap else 0)
+    mp.spawn(_worker, args=(world, port, W, H, strip, frames, out, overlap), nprocs=world, join=True)
     got = np.load(out)
     sc = rt.scenes
     scene = sc.scene_mesh(12, 6, env_size=8)
