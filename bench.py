@@ -82,7 +82,7 @@ def main():
     ap.add_argument("--mf-chunk-quads", type=int, default=None, help="kernel 3: 40-triangle quads per work item")
     ap.add_argument("--mf-group-quads", type=int, default=None, help="kernel 3: quads sharing one local origin (1, 2, 4, 8, 16)")
     ap.add_argument("--debug-bounces", type=int, default=None, help="diagnostic: override the bounce limit of the configuration (not the named workload)")
-    ap.add_argument("--strip-rows", type=int, default=16)
+    ap.add_argument("--strip-rows", type=int, default=8, help="rows per interleaved strip (multiple of 8); 8 balances the ranks to +-3%% at N = 8, 16 to +-6%%")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sync-each-frame", action="store_true", help="diagnostic: host waits for every frame")
     ap.add_argument("--no-kernel-timing", action="store_true", help="diagnostic: no HIP events around the scan launches")

@@ -7,9 +7,11 @@ sc = rt.scenes
 cfg = sc.CONFIGS["C2"]; W, H = cfg["width"], cfg["height"]; scene = cfg["scene"]()
 base = cfg["params"]()
 t1 = None
+STRIP = int(os.environ.get("STRIP", "16"))
+ALL = os.environ.get("ALL_RANKS", "0") == "1"
 for world in (1, 2, 4, 8):
-    for rank in sorted({0, world - 1}):
-        ctx = rt.host.Context(W, H, device=0, rank=rank, world=world, strip_rows=16)
+    for rank in (range(world) if ALL and world == 8 else sorted({0, world - 1})):
+        ctx = rt.host.Context(W, H, device=0, rank=rank, world=world, strip_rows=STRIP)
         ctx.upload_scene(scene)
         g = sc.GlibcRand(0); ps = [base.replace(frames=f, random=g.rand()) for f in range(1, 34)]
         for p in ps[:3]: ctx.render(p, sync=False)
