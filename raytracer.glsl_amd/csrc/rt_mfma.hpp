@@ -212,8 +212,14 @@ __device__ __forceinline__ void mf_flush(const MfFlushArgs &f, const uint32_t *q
 // pairs the exact test accepts are logged -- the log must stay empty, anything in it is a hole in mf_margin()
 struct MfVerifyLog { uint32_t n; uint32_t pad[3]; float ev[64][16]; };
 
+#ifndef MF_EXAMINE_GAP
+#define MF_EXAMINE_GAP 0     // s_nop operand of the fence behind the products (the compiler pads it to 8 wait states)
+#endif
+#ifndef MF_ISSUE_GAP
+#define MF_ISSUE_GAP -1      // >= 0: an s_nop in front of the products (distance between the last VALU read and the overwrite of a block)
+#endif
 #ifndef MF_MIN_BLOCKS
-#define MF_MIN_BLOCKS 4      // waves per SIMD the register allocator must allow: 128 VGPRs (16 spilled in the cold paths), measured +2% over 3 waves
+#define MF_MIN_BLOCKS 3      // waves per SIMD the register allocator must allow (four accumulator sets: 64 VGPRs)
 #endif
 template <int S, bool kCount, bool kVerify = false>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MF_MIN_BLOCKS))) intersect_mfma_kernel(SceneView sc, WaveBuffers wb, MfView mf, uint32_t bounce,
@@ -229,10 +235,12 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MF_MIN
     const RayQueue qin = (bounce & 1u) ? wb.q[1] : wb.q[0];
     unsigned long long *best = (bounce & 1u) ? wb.best[1] : wb.best[0];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, col = lane & 31, half = lane >> 5;
-    const uint32_t q_begin = blockIdx.y * chunk_quads, q_end = min(q_begin + chunk_quads, mf.n_quads);
+    // only quads that hold triangles; the padding rows inside the last one carry a -3e38 bias and never survive
+    const uint32_t q_begin = blockIdx.y * chunk_quads, q_end = min(q_begin + chunk_quads, min(mf.n_quads, (sc.n_tri_visits + kMfQuadTris - 1u) / kMfQuadTris));
     const uint32_t tile_begin = q_begin * kMfQuadTiles;
     const uint32_t v_chunk_begin = q_begin * kMfQuadTris, v_chunk_end = min(q_end * (uint32_t)kMfQuadTris, sc.n_tri_visits);
     const uint32_t group_mask = mf.group_quads - 1u, group_shift = (uint32_t)__builtin_ctz(mf.group_quads);
+    if (q_begin >= q_end) return;                             // (cannot happen: every chunk starts with a group that holds triangles)
     constexpr uint32_t kRaysPerBlock = 4u * S * 32u;
     unsigned long long c_cand_total = 0;
     uint32_t *queue = lds_queue + wave * kQueue;
@@ -282,9 +290,93 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MF_MIN
         };
         bf16x8 B[S];
         float thresh[S];
+        f32x16 accX[S], accY[S];
+        uint32_t pend_tile = 0u; bool have_pend = false;                  // wave-uniform: the tile whose products wait in accY
+        const f32x16 zero = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+        // five v_min3 per ray set and lane, two v_max3, one compare: "does any triangle of this lane survive"
+        auto minima = [&](int s, const f32x16 &acc, float (&mn)[5]) -> bool {
+#pragma unroll
+            for (int u = 0; u < 5; ++u) mn[u] = __builtin_fminf(__builtin_fminf(acc[3 * u], acc[3 * u + 1]), acc[3 * u + 2]);
+            // A finite threshold means finite operands and edge values below 2^7 * 1e30 in magnitude, hence finite
+            // minima: max-of-minima is then exactly "some triangle of this lane survives".  A NaN threshold passes all.
+            const float mx = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(mn[0], mn[1]), mn[2]), mn[3]), mn[4]);   // two v_max3
+            return !(mx <= thresh[s]);
+        };
+        // rare path: some lane has a survivor in `tile` -> per (ray set, triangle) ballots, survivors into the wave's LDS queue
+        auto park = [&](uint32_t tile, const f32x16 (&acc)[S], const float (&mn)[S][5]) {
+            if (kVerify) {
+                MfVerifyLog *log = reinterpret_cast<MfVerifyLog *>(reinterpret_cast<char *>(counters) + 64);
+                for (int s = 0; s < S; ++s)
+                    for (int u = 0; u < 5; ++u) {
+                        const uint32_t pos = v_chunk_begin + (tile - tile_begin) * kMfTileTris + 5u * (uint32_t)half + (uint32_t)u;
+                        if (pos < v_chunk_end && ray[s].valid && mn[s][u] <= thresh[s]) {
+                            const uint32_t v = mf.order[pos];
+                            TriRay tr; tr.o = ray[s].o; tr.d = ray[s].d; tr.cv = cross3(tr.d, tr.o); tr.ncv = tr.nd = 0.0f;
+                            const float t = tri_exact(sc.tri_edges[v], sc.tri_planes[v], tr);
+                            if (kEps < t && t < kInf) {
+                                const uint32_t at = atomicAdd(&log->n, 1u);
+                                if (at < 64u) {
+                                    float *e = log->ev[at];
+                                    e[0] = (float)(wave_slot0 + s * 32 + col); e[1] = (float)v; e[2] = (float)pos; e[3] = (float)((tile / kMfQuadTiles) >> group_shift);
+                                    e[4] = acc[s][3 * u]; e[5] = acc[s][3 * u + 1]; e[6] = acc[s][3 * u + 2]; e[7] = thresh[s];
+                                    e[8] = tr.o.x; e[9] = tr.o.y; e[10] = tr.o.z; e[11] = tr.d.x; e[12] = tr.d.y; e[13] = tr.d.z; e[14] = t; e[15] = (float)bounce;
+                                }
+                            }
+                        }
+                    }
+            }
+#pragma unroll
+            for (int s = 0; s < S; ++s)
+#pragma unroll
+                for (int u = 0; u < 5; ++u) {
+                    const unsigned long long m = __builtin_amdgcn_ballot_w64(!(mn[s][u] <= thresh[s]));
+                    if (m) {                                                        // wave-uniform
+                        if ((m >> lane) & 1ull) {
+                            const uint32_t v_off = (tile - tile_begin) * kMfTileTris + 5u * (uint32_t)half + (uint32_t)u;
+                            queue[qn + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = ((uint32_t)(s * 32 + col) << 16) | v_off;
+                        }
+                        qn += (uint32_t)__popcll(m);
+                    }
+                }
+        };
+        // the common "nothing survived" case costs 8 VALU per product + 1 branch per tile
+        auto examine = [&](uint32_t tile, f32x16 (&acc)[S]) {
+            float mn[S][5];
+            bool any_lane = false;
+#pragma unroll
+            for (int s = 0; s < S; ++s) any_lane |= minima(s, acc[s], mn[s]);
+            if (__builtin_amdgcn_ballot_w64(any_lane) != 0ull) park(tile, acc, mn);
+        };
+        // One pipeline stage: the S products of the NEXT tile are issued back to back, then the PENDING tile (whose products were
+        // issued one stage ago) is examined while they run: its 16 VALU instructions overlap the second matrix instruction
+        // instead of following it.  `nxt` and `pend` are the two accumulator sets.
+        //
+        // HAZARD FENCE.  All four accumulators pass through the asm statement behind the products: they
+        // stay in distinct registers for the whole loop, and the examination cannot move in front of the products.  The first
+        // versions of this kernel let the compiler reuse one register block for consecutive products -- "mfma v[18:33]; s_nop;
+        // 5 x v_min3 reading v18..v32; mfma v[18:33]" -- and a few times per 10^8 tiles the lanes 16-31 / 48-63 of one tile saw
+        // wrong values (spurious or LOST survivors, i.e. lost hits, different in every run).  Also NOT done, although
+        // tools/mfma_shadow_probe.hip shows that 5-6 independent VALU instructions issue for free right behind an MFMA:
+        // examining one ray set directly behind each matrix instruction ("mfma; 8 VALU; mfma; 8 VALU") brought the fault back at
+        // 10x the rate (and was slower).  What every faulty variant had and no clean one: a VALU read of a register directly
+        // followed by a matrix instruction that overwrites it (there: the compare on a temporary kept in the dead part of the
+        // next accumulator), and VALU reads of accumulators less than 8 wait states behind the last matrix instruction.  The
+        // mechanism is not established; this form repeats its survivor set exactly (scripts/dbg_cand.py, scripts/dbg_soak.py,
+        // tests/test_gpu_fullsize.py).
+        auto stage = [&](const uint4 &a, f32x16 (&nxt)[S], bool examine_pending, uint32_t pending_tile, f32x16 (&pend)[S]) {
+            const bf16x8 Aop = __builtin_bit_cast(bf16x8, a);
+#if MF_ISSUE_GAP >= 0
+            asm volatile("s_nop %0" :: "n"(MF_ISSUE_GAP) : "memory");          // no register operands: pinning the accumulators here cost 5%
+#endif
+#pragma unroll
+            for (int s = 0; s < S; ++s) nxt[s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Aop, B[s], zero, 0, 0, 0);
+            asm volatile("s_nop %4" : "+v"(accX[0]), "+v"(accX[S - 1]), "+v"(accY[0]), "+v"(accY[S - 1]) : "n"(MF_EXAMINE_GAP));
+            if (examine_pending) examine(pending_tile, pend);                            // wave-uniform condition
+        };
         auto step = [&](uint32_t q, uint4 (&a_cur)[kMfQuadTiles], uint4 (&a_nxt)[kMfQuadTiles]) {
             fetch_quad(a_nxt);
             if ((q & group_mask) == 0u) {                                     // first quad of a group: new local origin and bounds
+                if (have_pend) { examine(pend_tile, accY); have_pend = false; }  // judged by ITS group's thresholds, before they go
                 const ConstFloats gp = groups_k + (size_t)(q >> group_shift) * (sizeof(MfGroup) / 4);   // wave-uniform: scalar loads
                 MfGroup G;
                 G.cx = gp[0]; G.cy = gp[1]; G.cz = gp[2]; G.E = gp[3]; G.Ml = gp[4]; G.Pw = gp[5]; G.P = gp[6]; G.pad1 = 0.0f;
@@ -306,77 +398,15 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MF_MIN
                     B[s] = __builtin_bit_cast(bf16x8, bw);
                 }
             }
-#pragma unroll
-            for (int t = 0; t < kMfQuadTiles; ++t) {
-                const uint32_t tile = q * kMfQuadTiles + t;
-                if (tile * kMfTileTris >= n_tri_visits) break;                           // wave-uniform
-                if (t == kMfQuadTiles / 2 && qn >= kDrain) flush();
-                const bf16x8 Aop = __builtin_bit_cast(bf16x8, a_cur[t]);
-                // all S products first (back to back on the matrix pipe), then five v_min3 per ray set and lane, and ONE
-                // compare on the max of the minima: the common "nothing survived" case costs 8 VALU + 1 branch per MFMA
-                f32x16 acc[S];
-                float mn[S][5];
-                bool any_lane = false;
-#pragma unroll
-                for (int s = 0; s < S; ++s) {
-                    const f32x16 zero = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-                    acc[s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Aop, B[s], zero, 0, 0, 0);
-                }
-                // HAZARD FENCE.  Both accumulators pass through this (empty but for 4 wait states) asm statement, which (a) keeps
-                // them in distinct registers, (b) puts every VALU read of a result behind BOTH matrix instructions and (c) adds
-                // slack to the compiler's exact wait-state count.  Without it the compiler reused one register block:
-                //   mfma v[18:33] ; s_nop ; 5 x v_min3 reading v18..v32 ; mfma v[18:33]   <- issued right behind the last read
-                // and a few times per 10^8 tiles the lanes 16-31 / 48-63 of one tile saw wrong values (spurious or LOST
-                // survivors, i.e. lost hits; run-to-run different).  The mechanism is not established; every
-                // variant with the reads behind both matrix instructions was clean, every variant without was not.  With the
-                // fence the survivor set is identical in every run (scripts/dbg_cand.py, scripts/dbg_soak.py).
-                asm volatile("s_nop 3" : "+v"(acc[0]), "+v"(acc[S - 1]));
-#pragma unroll
-                for (int s = 0; s < S; ++s) {
-#pragma unroll
-                    for (int u = 0; u < 5; ++u) mn[s][u] = __builtin_fminf(__builtin_fminf(acc[s][3 * u], acc[s][3 * u + 1]), acc[s][3 * u + 2]);
-                    // A finite threshold means finite operands and edge values below 2^7 * 1e30 in magnitude, hence finite
-                    // minima: max-of-minima is then exactly "some triangle of this lane survives".  A NaN threshold passes all.
-                    const float mx = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(mn[s][0], mn[s][1]), mn[s][2]), mn[s][3]), mn[s][4]);   // two v_max3
-                    any_lane |= !(mx <= thresh[s]);
-                }
-                if (kVerify) {
-                    MfVerifyLog *log = reinterpret_cast<MfVerifyLog *>(reinterpret_cast<char *>(counters) + 64);
-                    for (int s = 0; s < S; ++s)
-                        for (int u = 0; u < 5; ++u) {
-                            const uint32_t pos = v_chunk_begin + (tile - tile_begin) * kMfTileTris + 5u * (uint32_t)half + (uint32_t)u;
-                            if (pos < v_chunk_end && ray[s].valid && mn[s][u] <= thresh[s]) {
-                                const uint32_t v = mf.order[pos];
-                                TriRay tr; tr.o = ray[s].o; tr.d = ray[s].d; tr.cv = cross3(tr.d, tr.o); tr.ncv = tr.nd = 0.0f;
-                                const float t = tri_exact(sc.tri_edges[v], sc.tri_planes[v], tr);
-                                if (kEps < t && t < kInf) {
-                                    const uint32_t at = atomicAdd(&log->n, 1u);
-                                    if (at < 64u) {
-                                        float *e = log->ev[at];
-                                        e[0] = (float)(wave_slot0 + s * 32 + col); e[1] = (float)v; e[2] = (float)pos; e[3] = (float)(q >> group_shift);
-                                        e[4] = acc[s][3 * u]; e[5] = acc[s][3 * u + 1]; e[6] = acc[s][3 * u + 2]; e[7] = thresh[s];
-                                        e[8] = tr.o.x; e[9] = tr.o.y; e[10] = tr.o.z; e[11] = tr.d.x; e[12] = tr.d.y; e[13] = tr.d.z; e[14] = t; e[15] = (float)bounce;
-                                    }
-                                }
-                            }
-                        }
-                }
-                if (__builtin_amdgcn_ballot_w64(any_lane) != 0ull) {
-#pragma unroll
-                    for (int s = 0; s < S; ++s)
-#pragma unroll
-                        for (int u = 0; u < 5; ++u) {
-                            const unsigned long long m = __builtin_amdgcn_ballot_w64(!(mn[s][u] <= thresh[s]));
-                            if (m) {                                                        // wave-uniform
-                                if ((m >> lane) & 1ull) {
-                                    const uint32_t v_off = (tile - tile_begin) * kMfTileTris + 5u * (uint32_t)half + (uint32_t)u;
-                                    queue[qn + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = ((uint32_t)(s * 32 + col) << 16) | v_off;
-                                }
-                                qn += (uint32_t)__popcll(m);
-                            }
-                        }
-                }
-            }
+            // Software pipeline over tiles (see stage()): two accumulator sets alternate; the one left pending at the end of a
+            // step is always accY.
+            const uint32_t tile0 = q * kMfQuadTiles;
+            stage(a_cur[0], accX, have_pend, pend_tile, accY);
+            stage(a_cur[1], accY, true, tile0, accX);
+            if (qn >= kDrain) flush();
+            stage(a_cur[2], accX, true, tile0 + 1u, accY);
+            stage(a_cur[3], accY, true, tile0 + 2u, accX);
+            pend_tile = tile0 + 3u; have_pend = true;
         };
         uint4 a0[kMfQuadTiles], a1[kMfQuadTiles];
         fetch_quad(a0);
@@ -388,6 +418,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MF_MIN
                 if (qn >= kDrain) flush();
             }
         }
+        if (have_pend) examine(pend_tile, accY);
         flush();
         const uint32_t n_cand = (lane == 0) ? n_total : 0u;
         c_cand_total += n_cand;
