@@ -216,7 +216,7 @@ struct MfVerifyLog { uint32_t n; uint32_t pad[3]; float ev[64][16]; };
 #define MF_EXAMINE_GAP 0     // s_nop operand of the fence behind the products (the compiler pads it to 8 wait states)
 #endif
 #ifndef MF_ISSUE_GAP
-#define MF_ISSUE_GAP -1      // >= 0: an s_nop in front of the products (distance between the last VALU read and the overwrite of a block)
+#define MF_ISSUE_GAP 1       // s_nop operand in front of the products: >= 2 wait states between the last VALU read and the overwrite of a block (-1: none)
 #endif
 #ifndef MF_MIN_BLOCKS
 #define MF_MIN_BLOCKS 3      // waves per SIMD the register allocator must allow (four accumulator sets: 64 VGPRs)
