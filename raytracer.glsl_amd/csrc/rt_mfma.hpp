@@ -244,7 +244,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MF_MIN
     constexpr uint32_t kRaysPerBlock = 4u * S * 32u;
     unsigned long long c_cand_total = 0;
     uint32_t *queue = lds_queue + wave * kQueue;
-    const uint32_t n_tri_visits = sc.n_tri_visits;
     MfFlushArgs fa{qin.a, qin.b, sc.tri_edges, sc.tri_planes, best, mf.order, 0u, v_chunk_begin, v_chunk_end, debug_skip_exact, mf.dbg_log};
     // group records through the constant address space: uniform index => s_load, which neither waits on nor is held up by
     // the vector-memory counter the A-tile prefetch uses

@@ -573,6 +573,7 @@ __global__ void __launch_bounds__(256) shade_kernel(SceneView sc, FrameParams P,
     unsigned long long *best_out = (bounce & 1u) ? wb.best[0] : wb.best[1];
     const bool last_bounce = (bounce + 1u >= P.max_bounce);
     unsigned long long c_env = 0;
+    __shared__ uint32_t s_cnt[5];
     for (uint32_t blk = blockIdx.x; blk * 256u < n_rays; blk += gridDim.x) {      // grid-stride, see intersect_kernel
     const uint32_t slot = blk * 256u + threadIdx.x;
     const bool valid = slot < n_rays;
@@ -599,19 +600,26 @@ __global__ void __launch_bounds__(256) shade_kernel(SceneView sc, FrameParams P,
         }
         if (!alive) finish_path(P, im, wb, s, rng_out);
     }
+    // compaction: ballot + prefix popcount inside the wave, the four wave totals summed through LDS, ONE atomicAdd per block on
+    // the next queue's counter (every wave of the launch adding to that one address was the kernel's bottleneck: 32k atomics on
+    // the camera-ray bounce)
     const unsigned long long mask = __ballot(alive);
-    if (mask) {
-        const int lane = threadIdx.x & 63;
-        const int leader = (int)__builtin_ctzll(mask);
-        uint32_t wave_base = 0;
-        if (lane == leader) wave_base = atomicAdd(&wb.counts[bounce + 1u], (uint32_t)__popcll(mask));
-        wave_base = __shfl(wave_base, leader);
-        if (alive) {
-            const uint32_t out_slot = wave_base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-            store_ray(qout, out_slot, s);
-            best_out[out_slot] = kNoHitKey;
-        }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) s_cnt[wave] = (uint32_t)__popcll(mask);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t total = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+        s_cnt[4] = total ? atomicAdd(&wb.counts[bounce + 1u], total) : 0u;
     }
+    __syncthreads();
+    if (alive) {
+        uint32_t wave_base = s_cnt[4];
+        for (int w = 0; w < wave; ++w) wave_base += s_cnt[w];
+        const uint32_t out_slot = wave_base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+        store_ray(qout, out_slot, s);
+        best_out[out_slot] = kNoHitKey;
+    }
+    __syncthreads();                                                              // s_cnt is rewritten by the next batch
     }
     if (kCount) {
         atomicAdd(&counters->env_lookups, c_env);
