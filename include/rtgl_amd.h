@@ -67,7 +67,8 @@ typedef struct rtgl_counters {
     uint64_t reserved[3];
 } rtgl_counters;
 
-/* Kernel variants (rtgl_set_option "kernel").  All produce bit-identical images. */
+/* Kernel variants (rtgl_set_option "kernel"; the environment variable RTGL_AMD_KERNEL=0..3 changes the default of new
+ * contexts).  All produce bit-identical images. */
 enum {
     RTGL_KERNEL_MEGA = 0,            /* one launch per frame, one lane per pixel, whole path in registers */
     RTGL_KERNEL_WAVEFRONT = 1,       /* one fused launch per bounce over the compacted ray queue */

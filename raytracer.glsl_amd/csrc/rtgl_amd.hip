@@ -248,6 +248,8 @@ extern "C" int rtgl_create_tiled(rtgl_context **out, int width, int height, int 
     CCHK(hipMemsetAsync(ctx->d_counters, 0, 64 + sizeof(MfVerifyLog), ctx->stream));
     CCHK(hipStreamSynchronize(ctx->stream));
 #undef CCHK
+    // operational override of the default scan without touching the caller: RTGL_AMD_KERNEL=0..3 (rtgl_set_option still wins)
+    if (const char *k = getenv("RTGL_AMD_KERNEL")) { const int v = atoi(k); if (v >= RTGL_KERNEL_MEGA && v <= RTGL_KERNEL_WAVEFRONT_MFMA) ctx->opt_kernel = v; }
     *out = ctx;
     return RTGL_OK;
 }
