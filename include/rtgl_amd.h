@@ -134,7 +134,8 @@ int rtgl_read_rng_state(rtgl_context *ctx, uint32_t *xyzw);    /* per local pixe
  * that use the wave-level edge short circuit), "wf_packed" (v_pk_fma_f32 ray pairs on/off), "mf_sets" (32-ray sets
  * per wave of the kernel-3 scan: 2), "mf_chunk_quads" (40-triangle quads per work item), "mf_group_quads" (quads
  * sharing one local origin: a power of two up to 64; changing it rebuilds the broad-phase data at the next frame),
- * "rng_state", "counters", "kernel_timing" */
+ * "rng_state", "counters", "kernel_timing" (0 off; N > 0: every N-th frame since the last rtgl_timing_reset carries HIP
+ * event pairs around its dominant-kernel launches) */
 int rtgl_set_option(rtgl_context *ctx, const char *key, int value);
 int rtgl_get_option(rtgl_context *ctx, const char *key, int *value);
 /* elapsed GPU milliseconds of the last rtgl_render_frame (HIP events on the context's stream) */

@@ -182,6 +182,7 @@ struct rtgl_context {
     uint32_t *d_counts = nullptr; uint32_t counts_capacity = 0;
     uint32_t *h_counts = nullptr;            // pinned: ray counts per bounce of the most recent finished frame
     hipEvent_t counts_ev = nullptr; bool counts_pending = false, counts_valid = false;
+    bool timing_this_frame = false; uint32_t timing_frame_counter = 0;
     uint32_t counts_n0 = 0, counts_len = 0;
     std::vector<uint32_t> est_counts;        // grid-size estimates for the next frame
     WaveBuffers wb{};
@@ -472,7 +473,7 @@ static int rebuild_triangles(rtgl_context *ctx)
 // event pair around one dominant-kernel launch (only with option kernel_timing)
 static void kev_mark(rtgl_context *ctx)
 {
-    if (!ctx->opt_kernel_timing) return;
+    if (!ctx->timing_this_frame) return;
     if (ctx->kev_used == ctx->kev.size()) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return; ctx->kev.push_back(e); }
     (void)hipEventRecord(ctx->kev[ctx->kev_used++], ctx->stream);
 }
@@ -685,7 +686,9 @@ extern "C" int rtgl_render_frame(rtgl_context *ctx)
     const bool use_wavefront = ctx->opt_kernel != RTGL_KERNEL_MEGA && P.max_bounce > 0;
     if (use_wavefront && n0 > 0) { int rc = ensure_wave_buffers(ctx, n0, P.max_bounce, P.samples > 1); if (rc) return rc; }
     HIPCHK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
-    if (ctx->opt_kernel_timing) {
+    // option kernel_timing = N: every N-th frame since the last reset carries the event pairs (each pair costs ~3 us of gap)
+    ctx->timing_this_frame = ctx->opt_kernel_timing > 0 && (ctx->timing_frame_counter++ % (uint32_t)ctx->opt_kernel_timing) == 0u;
+    if (ctx->timing_this_frame) {
         if (ctx->kev_frame_start.size() >= 4096) { ctx->kev_used = 0; ctx->kev_frame_start.clear(); }   // bounded history
         ctx->kev_frame_start.push_back(ctx->kev_used);
         kev_mark(ctx);                                   // frame begin
@@ -766,7 +769,7 @@ extern "C" int rtgl_timing_reset(rtgl_context *ctx)
 {
     ENTER(ctx);
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    ctx->kev_used = 0; ctx->kev_frame_start.clear();
+    ctx->kev_used = 0; ctx->kev_frame_start.clear(); ctx->timing_frame_counter = 0;
     return RTGL_OK;
 }
 
@@ -915,7 +918,8 @@ extern "C" int rtgl_set_option(rtgl_context *ctx, const char *key, int value)
     else if (!strcmp(key, "counters")) ctx->opt_counters = value != 0;
     else if (!strcmp(key, "kernel_timing")) {
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-        ctx->opt_kernel_timing = value != 0; ctx->kev_used = 0; ctx->kev_frame_start.clear();
+        if (value < 0) return fail(ctx, RTGL_ERR_INVALID, "kernel_timing must be 0 (off) or the sampling period in frames");
+        ctx->opt_kernel_timing = value; ctx->kev_used = 0; ctx->kev_frame_start.clear(); ctx->timing_frame_counter = 0; ctx->timing_this_frame = false;
     } else return fail(ctx, RTGL_ERR_INVALID, std::string("unknown option ") + key);
     return RTGL_OK;
 }

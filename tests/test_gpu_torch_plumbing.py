@@ -42,6 +42,15 @@ def test_render_into_torch_tensor_on_torch_stream(rt):
     assert 0.0 < t["intersect_ms"] <= t["frame_ms"]
     got = full.cpu().numpy()
     assert (got.view(np.uint32) == want.view(np.uint32)).all()
+    # sampled timing: with period 2 every other frame carries the event pairs
+    with torch.cuda.stream(side):
+        ctx.set_option("kernel_timing", 2)
+        ctx.timing_reset()
+        for p in gc.frame_sequence(sc, sc.params_c2(), 5):
+            ctx.render(p, sync=False)
+        side.synchronize()
+        t2 = ctx.accumulated_timing()
+    assert t2["frames"] == 3 and t2["intersect_launches"] == 3 * frames[0].max_bounce
     # detach again before the tensor goes away
     ctx.bind_device_image(0)
     ctx.set_stream(0)
