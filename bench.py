@@ -193,10 +193,10 @@ def main():
         if scan_launches == 0:            # a scene without triangles has no scan launches: describe the whole frame instead
             launches_per_frame, avg_launch_s, bytes_per_launch = 1, frame_ms / 1e3 / args.steps, alg["total"] * share
         flops_per_launch = cnt["triangle_tests"] * 36.0 * share / launches_per_frame   # 18 fma per edge-function triple
-        kname = {0: "pathtrace_mega_kernel", 1: "bounce_kernel", 2: "intersect_kernel", 3: "intersect_mfma_kernel"}[ctx.get_option("kernel")]
+        kname = {0: "pathtrace_mega_kernel", 1: "bounce_kernel", 2: "intersect_kernel", 3: "intersect_mfma_kernel"}[ctx.get_option("kernel_in_use")]
         if scan_launches == 0:
             kname = "whole frame (generate_rays + shade)"
-        k = ctx.get_option("kernel")
+        k = ctx.get_option("kernel_in_use")
         gtests = cnt["triangle_tests"] * share / launches_per_frame / avg_launch_s / 1e9
         tflops = flops_per_launch / avg_launch_s / 1e12
         if k == 3:
@@ -226,7 +226,7 @@ def main():
                                    f"{scene.spheres.shape[0]} spheres, cube map {scene.env.shape[1] if scene.env is not None else 0}^2, "
                                    f"1 spp/frame progressive, dof={base.use_dof}",
                        "parallelism": f"{world} GPU(s), {args.strip_rows}-row strips interleaved, gather to rank 0 every frame" + (" (asynchronous, overlapped with the next frame)" if world > 1 else ""),
-                       "kernel": ctx.get_option("kernel"), "wf_rays": ctx.get_option("wf_rays"), "wf_mode": ctx.get_option("wf_mode"), "wf_chunk": ctx.get_option("wf_chunk"), "wf_early": ctx.get_option("wf_early"), "wf_packed": ctx.get_option("wf_packed"),
+                       "kernel": ctx.get_option("kernel_in_use"), "wf_rays": ctx.get_option("wf_rays"), "wf_mode": ctx.get_option("wf_mode"), "wf_chunk": ctx.get_option("wf_chunk"), "wf_early": ctx.get_option("wf_early"), "wf_packed": ctx.get_option("wf_packed"),
                        "mf_sets": ctx.get_option("mf_sets"), "mf_group_quads": ctx.get_option("mf_group_quads"), "mf_chunk_quads": ctx.get_option("mf_chunk_quads")},
             "roofline": {"bound": "hbm", "achieved": bytes_per_launch / avg_launch_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": bytes_per_launch / avg_launch_s / 1e9 / HBM_PEAK_GBS, "traffic": traffic,

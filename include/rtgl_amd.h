@@ -68,7 +68,8 @@ typedef struct rtgl_counters {
 } rtgl_counters;
 
 /* Kernel variants (rtgl_set_option "kernel"; the environment variable RTGL_AMD_KERNEL=0..3 changes the default of new
- * contexts).  All produce bit-identical images. */
+ * contexts).  All produce bit-identical images.  Unless a variant was requested explicitly, a scene without triangles is rendered
+ * with RTGL_KERNEL_MEGA (there is no scan to split off; one launch per frame). */
 enum {
     RTGL_KERNEL_MEGA = 0,            /* one launch per frame, one lane per pixel, whole path in registers */
     RTGL_KERNEL_WAVEFRONT = 1,       /* one fused launch per bounce over the compacted ray queue */
@@ -137,7 +138,7 @@ int rtgl_read_rng_state(rtgl_context *ctx, uint32_t *xyzw);    /* per local pixe
  * "rng_state", "counters", "kernel_timing" (0 off; N > 0: every N-th frame since the last rtgl_timing_reset carries HIP
  * event pairs around its dominant-kernel launches) */
 int rtgl_set_option(rtgl_context *ctx, const char *key, int value);
-int rtgl_get_option(rtgl_context *ctx, const char *key, int *value);
+int rtgl_get_option(rtgl_context *ctx, const char *key, int *value);   /* also "kernel_in_use": the variant the last frame ran */
 /* elapsed GPU milliseconds of the last rtgl_render_frame (HIP events on the context's stream) */
 int rtgl_last_frame_ms(rtgl_context *ctx, float *ms);
 /* Per-kernel GPU time of the last frame, from HIP events recorded around every launch of the dominant
