@@ -102,3 +102,25 @@ def test_mesh_10k_crop(rt, oracle):
     r = run_both(rt, oracle, sc.scene_mesh(100, 50, env_size=64), sc.params_c2(), 96, 64, frames=1)
     assert_bit_exact(r, 96, 64)
     assert r["cnt_g"]["triangle_tests"] == r["cnt_o"]["triangle_tests"]
+
+
+def test_triangle_free_scene_defaults_to_the_megakernel_and_explicit_choice_wins(rt, oracle):
+    sc = rt.scenes
+    scene, p = sc.scene_c1(), sc.params_c1().replace(frames=1, random=sc.GlibcRand(0).rand())
+    want = np.zeros((64, 64, 4), np.float32)
+    oracle.render(scene, p, want, threads=4)
+    for explicit, expect in ((None, 0), (3, 3), (2, 2)):
+        ctx = rt.host.Context(64, 64)
+        if explicit is not None:
+            ctx.set_option("kernel", explicit)
+        ctx.upload_scene(scene)
+        ctx.render(p)
+        assert ctx.get_option("kernel_in_use") == expect
+        assert (ctx.read_image().view(np.uint32) == want.view(np.uint32)).all()
+        ctx.close()
+    mesh = sc.scene_mesh(8, 4, env_size=8)
+    ctx = rt.host.Context(64, 64)
+    ctx.upload_scene(mesh)
+    ctx.render(sc.params_c2().replace(frames=1, random=1))
+    assert ctx.get_option("kernel_in_use") == 3
+    ctx.close()
