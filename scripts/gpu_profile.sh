@@ -3,6 +3,7 @@ set -e
 TAG=${1:-r1}; shift || true
 R=$GRAFT_REPO_ROOT; [ -z "$R" ] && R=$(pwd)
 OUT=$R/gpurun_out/prof_$TAG
+rm -rf $OUT          # stale runs of the same tag would be picked up by the summariser
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline "$@" > $OUT/bench_trace.json 2> $OUT/trace.err || (tail -20 $OUT/trace.err; exit 1)
