@@ -17,11 +17,11 @@ import sys
 tag, config = sys.argv[1], (sys.argv[2] if len(sys.argv) > 2 else "C2")
 src, dst = f"gpurun_out/prof_{tag}", f"profiles/{tag}"
 os.makedirs(dst, exist_ok=True)
-shutil.copy(glob.glob(f"{src}/trace/runc/*_kernel_stats.csv")[0], f"{dst}/kernel_stats.csv")
+shutil.copy(max(glob.glob(f"{src}/trace/runc/*_kernel_stats.csv"), key=os.path.getmtime), f"{dst}/kernel_stats.csv")
 shutil.copy(f"{src}/bench_trace.json", f"{dst}/bench_under_rocprof.json")
 out = {}
 for sub in ("pmc_sq", "pmc_fetch", "pmc_write"):
-    f = glob.glob(f"{src}/{sub}/runc/*_counter_collection.csv")[0]
+    f = max(glob.glob(f"{src}/{sub}/runc/*_counter_collection.csv"), key=os.path.getmtime)   # gpurun merges runs of the same tag: newest wins
     agg = collections.defaultdict(lambda: collections.defaultdict(float))
     dur, calls, seen = collections.defaultdict(float), collections.Counter(), set()
     for r in csv.DictReader(open(f)):
