@@ -83,6 +83,7 @@ def main():
     ap.add_argument("--mf-group-quads", type=int, default=None, help="kernel 3: quads sharing one local origin (1, 2, 4, 8, 16)")
     ap.add_argument("--debug-bounces", type=int, default=None, help="diagnostic: override the bounce limit of the configuration (not the named workload)")
     ap.add_argument("--strip-rows", type=int, default=8, help="rows per interleaved strip (multiple of 8); 8 balances the ranks to +-3%% at N = 8, 16 to +-6%%")
+    ap.add_argument("--timing-period", type=int, default=None, help="frames between kernel-timed frames (default: 1 at N = 1, 4 for N > 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sync-each-frame", action="store_true", help="diagnostic: host waits for every frame")
     ap.add_argument("--no-kernel-timing", action="store_true", help="diagnostic: no HIP events around the scan launches")
@@ -126,7 +127,7 @@ def main():
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     # HIP events around every launch of the dominant kernel: in every frame at N = 1, in every 4th frame for N > 1 (each event
     # pair is ~3 us of launch gap; a rank's frame is 8x shorter there)
-    timing_period = 0 if args.no_kernel_timing else (1 if world == 1 else 4)
+    timing_period = 0 if args.no_kernel_timing else (args.timing_period or (1 if world == 1 else 4))
     ctx.set_option("kernel_timing", timing_period)
 
     rnd = sc.GlibcRand(0)
@@ -159,12 +160,14 @@ def main():
     gat.finish()                           # the last frame's exchange and un-permute belong to the timed region
     barrier()
     dt = time.perf_counter() - t0
+    timed_frames = args.steps                              # frames the event timing covers
     if args.no_kernel_timing:
         frame_ms, scan_ms, scan_launches = dt * 1e3, dt * 1e3, args.steps * base.max_bounce
     else:
         t = ctx.accumulated_timing()                      # HIP events recorded on the launch stream around every scan launch
         frame_ms, scan_ms, scan_launches = t["frame_ms"], t["intersect_ms"], t["intersect_launches"]
-        assert t["frames"] == (args.steps + timing_period - 1) // timing_period
+        timed_frames = t["frames"]
+        assert timed_frames == (args.steps + timing_period - 1) // timing_period
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -187,11 +190,11 @@ def main():
         # dominant kernel = the ray x triangle scan (rank 0's launches; its share of the frame is 1/world)
         share = 1.0 / world
         alg = algorithmic_bytes(W, H, cnt, scene)
-        launches_per_frame = max(scan_launches // args.steps, 1)
+        launches_per_frame = max(scan_launches // max(timed_frames, 1), 1)
         avg_launch_s = max(scan_ms, 1e-9) / 1e3 / max(scan_launches, 1)
         bytes_per_launch = alg["scan"] * share / launches_per_frame
         if scan_launches == 0:            # a scene without triangles has no scan launches: describe the whole frame instead
-            launches_per_frame, avg_launch_s, bytes_per_launch = 1, frame_ms / 1e3 / args.steps, alg["total"] * share
+            launches_per_frame, avg_launch_s, bytes_per_launch = 1, frame_ms / 1e3 / max(timed_frames, 1), alg["total"] * share
         flops_per_launch = cnt["triangle_tests"] * 36.0 * share / launches_per_frame   # 18 fma per edge-function triple
         kname = {0: "pathtrace_mega_kernel", 1: "bounce_kernel", 2: "intersect_kernel", 3: "intersect_mfma_kernel"}[ctx.get_option("kernel_in_use")]
         if scan_launches == 0:
