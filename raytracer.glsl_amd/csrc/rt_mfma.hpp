@@ -357,9 +357,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MF_MIN
         // wrong values (spurious or LOST survivors, i.e. lost hits, different in every run).  Also NOT done, although
         // tools/mfma_shadow_probe.hip shows that 5-6 independent VALU instructions issue for free right behind an MFMA:
         // examining one ray set directly behind each matrix instruction ("mfma; 8 VALU; mfma; 8 VALU") brought the fault back at
-        // 10x the rate (and was slower) -- also with every temporary kept out of the accumulator blocks and 2-4 wait states in
-        // front of each matrix instruction, so a write-after-read on the overwritten block is not (all of) it.  What every faulty
-        // variant had and no clean one: VALU reads of accumulators issued within a few wait states behind a matrix instruction.
+        // 10x the rate (and was no faster: 3 waves per SIMD already overlap) -- also with every temporary kept out of the
+        // accumulator blocks, 2-8 wait states in front of each matrix instruction, up to 12 behind it, and compare masks given time
+        // before scalar code reads them.  What every faulty variant had and no clean one: an examination placed BETWEEN the two
+        // products of a tile.  tools/mfma_pipeline_probe.hip finds no fault in the same instruction patterns on known operands.
         // The mechanism is not established; this form (>= 8 wait states between the last product and the examination) repeats
         // its survivor set exactly (scripts/dbg_cand.py, scripts/dbg_soak.py, tests/test_gpu_fullsize.py).
         auto stage = [&](const uint4 &a, f32x16 (&nxt)[S], bool examine_pending, uint32_t pending_tile, f32x16 (&pend)[S]) {
