@@ -69,30 +69,42 @@ struct MfView {
 __host__ __device__ constexpr int mf_row(int rho, int h) { return (rho & 3) + 8 * (rho >> 2) + 4 * h; }
 
 // ---- upload time: local origins, bounds and the bf16 A matrices -------------------------------------------------
+// One wave per group: bounding box (wave reduction) -> local origin; the group's A region zero-filled with the padding bias;
+// one lane per triangle for the rows and the bounds (wave reduction of the maxima).
+__device__ __forceinline__ float wave_max(float x) { for (int off = 32; off > 0; off >>= 1) x = fmaxf(x, __shfl_xor(x, off)); return x; }
+__device__ __forceinline__ float wave_min(float x) { for (int off = 32; off > 0; off >>= 1) x = fminf(x, __shfl_xor(x, off)); return x; }
+
 __global__ void __launch_bounds__(64) prepare_mfma_kernel(const float4 *__restrict__ vertices, const uint32_t *__restrict__ visit_tri,
                                                           const uint32_t *__restrict__ order, uint32_t n_visits, uint32_t n_groups,
                                                           uint32_t group_quads, MfGroup *__restrict__ groups, uint4 *__restrict__ A)
 {
-    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t g = blockIdx.x, lane = threadIdx.x;
     if (g >= n_groups) return;
     const uint32_t group_tiles = group_quads * kMfQuadTiles, group_tris = group_tiles * kMfTileTris;
     const uint32_t v_begin = g * group_tris, v_end = min(v_begin + group_tris, n_visits);
     f3 lo = mk(__builtin_inff(), __builtin_inff(), __builtin_inff()), hi = mk(-__builtin_inff(), -__builtin_inff(), -__builtin_inff());
     bool bad = false;
-    for (uint32_t v = v_begin; v < v_end; ++v)
+    for (uint32_t v = v_begin + lane; v < v_end; v += 64u)
         for (int k = 0; k < 3; ++k) {
             float4 p = vertices[3 * (size_t)visit_tri[order[v]] + k];
             lo = mk(fminf(lo.x, p.x), fminf(lo.y, p.y), fminf(lo.z, p.z));
             hi = mk(fmaxf(hi.x, p.x), fmaxf(hi.y, p.y), fmaxf(hi.z, p.z));
             bad |= !(fabsf(p.x) < 1e18f) || !(fabsf(p.y) < 1e18f) || !(fabsf(p.z) < 1e18f);   // non-finite or so large that products overflow
         }
+    lo = mk(wave_min(lo.x), wave_min(lo.y), wave_min(lo.z));
+    hi = mk(wave_max(hi.x), wave_max(hi.y), wave_max(hi.z));
+    bad = __any(bad);
     const f3 c = mk(0.5f * lo.x + 0.5f * hi.x, 0.5f * lo.y + 0.5f * hi.y, 0.5f * lo.z + 0.5f * hi.z);
+    // [tile][panel][row][8 bf16]: everything zero except the bias (k = 6, panel 0) of -3e38: spare rows / missing triangles never survive
+    uint4 *region = A + (size_t)g * group_tiles * 64;
+    typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
+    bf16x2v biasv; biasv[0] = (__bf16)(-3.0e38f); biasv[1] = (__bf16)0.0f;
+    const uint32_t bias_word = __builtin_bit_cast(uint32_t, biasv);
+    for (uint32_t i = lane; i < group_tiles * 64u; i += 64u) region[i] = make_uint4(0u, 0u, 0u, (i & 32u) ? 0u : bias_word);
+    __syncthreads();
     float E = 0.0f, Ml = 0.0f, Pw = 0.0f, P = 0.0f;
-    __bf16 *rows = reinterpret_cast<__bf16 *>(A + (size_t)g * group_tiles * 64);        // [tile][panel][row][8]
-    for (uint32_t i = 0; i < group_tiles * 64 * 8; ++i) rows[i] = (__bf16)0.0f;
-    for (uint32_t t = 0; t < group_tiles; ++t)
-        for (int r = 0; r < 32; ++r) rows[(t * 64 + r) * 8 + 6] = (__bf16)(-3.0e38f);      // spare rows / missing triangles never survive
-    for (uint32_t v = v_begin; v < v_end; ++v) {
+    __bf16 *rows = reinterpret_cast<__bf16 *>(region);
+    for (uint32_t v = v_begin + lane; v < v_end; v += 64u) {
         const uint32_t tri = visit_tri[order[v]];                       // v = storage position
         f3 w[3], wl[3];
         for (int k = 0; k < 3; ++k) { float4 p = vertices[3 * (size_t)tri + k]; w[k] = mk(p.x, p.y, p.z); wl[k] = w[k] - c; }
@@ -118,6 +130,9 @@ __global__ void __launch_bounds__(64) prepare_mfma_kernel(const float4 *__restri
             row[6] = (__bf16)0.0f; row[7] = mh[0]; row1[6] = mh[1]; row1[7] = mh[2];
         }
     }
+    // fmaxf drops NaNs: a NaN norm (non-finite vertex) is covered by `bad`
+    E = wave_max(E); Ml = wave_max(Ml); P = wave_max(P); Pw = wave_max(Pw);
+    if (lane != 0) return;
     MfGroup G;
     G.cx = c.x; G.cy = c.y; G.cz = c.z;
     const float nanv = __builtin_nanf("");

@@ -462,7 +462,7 @@ static int rebuild_triangles(rtgl_context *ctx)
         if (a_bytes > 0xFFFF0000ull) return fail(ctx, RTGL_ERR_INVALID, "mesh too large for the 32-bit tile offsets of the kernel-3 scan");
         HIPCHK(ctx, hipMalloc((void **)&ctx->d_mf_A, a_bytes));
         HIPCHK(ctx, hipMemsetAsync(ctx->d_mf_A, 0, a_bytes, ctx->stream));
-        hipLaunchKernelGGL(prepare_mfma_kernel, dim3((ctx->n_mf_groups + 63) / 64), dim3(64), 0, ctx->stream, ctx->d_vertices, d_visit,
+        hipLaunchKernelGGL(prepare_mfma_kernel, dim3(ctx->n_mf_groups), dim3(64), 0, ctx->stream, ctx->d_vertices, d_visit,
                            ctx->d_mf_order, ctx->n_tri_visits, ctx->n_mf_groups, ctx->mf_group_quads, ctx->d_mf_groups, ctx->d_mf_A);
         HIPCHK(ctx, hipGetLastError());
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
