@@ -240,8 +240,8 @@ template <int S, bool kCount, bool kVerify = false>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MF_MIN_BLOCKS))) intersect_mfma_kernel(SceneView sc, WaveBuffers wb, MfView mf, uint32_t bounce,
                                                              uint32_t chunk_quads, Counters *__restrict__ counters, int debug_skip_exact)
 {
-    // grid: x = blocks of 4 waves x S ray sets x 32 rays (grid-stride), y = chunks of `chunk_quads` quads (a multiple of
-    // the group size, so a group never straddles two chunks)
+    // grid: x = blocks of 4 waves x S ray sets x 32 rays (grid-stride), y = chunks of `chunk_quads` quads (a chunk may start
+    // in the middle of a group: the group's origin and bounds are set up at the first quad of every chunk as well)
     // per-wave survivor queue, entry = (ray in wave) << 16 | triangle offset in chunk.  Half a loop step (2 tiles x S ray sets
     // x 5 triangles x 64 lanes) can add at most kStepMax entries, and the queue is drained between half steps once it holds kDrain
     constexpr uint32_t kStepMax = (kMfQuadTiles / 2) * S * 5 * 64, kDrain = 192, kQueue = kStepMax + kDrain;
@@ -255,7 +255,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MF_MIN
     const uint32_t tile_begin = q_begin * kMfQuadTiles;
     const uint32_t v_chunk_begin = q_begin * kMfQuadTris, v_chunk_end = min(q_end * (uint32_t)kMfQuadTris, sc.n_tri_visits);
     const uint32_t group_mask = mf.group_quads - 1u, group_shift = (uint32_t)__builtin_ctz(mf.group_quads);
-    if (q_begin >= q_end) return;                             // (cannot happen: every chunk starts with a group that holds triangles)
+    if (q_begin >= q_end) return;                             // chunk behind the last quad that holds triangles
     constexpr uint32_t kRaysPerBlock = 4u * S * 32u;
     unsigned long long c_cand_total = 0;
     uint32_t *queue = lds_queue + wave * kQueue;
@@ -390,7 +390,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MF_MIN
         };
         auto step = [&](uint32_t q, uint4 (&a_cur)[kMfQuadTiles], uint4 (&a_nxt)[kMfQuadTiles]) {
             fetch_quad(a_nxt);
-            if ((q & group_mask) == 0u) {                                     // first quad of a group: new local origin and bounds
+            if ((q & group_mask) == 0u || q == q_begin) {                     // first quad of a group or of this chunk: local origin and bounds of its group
                 if (have_pend) { examine(pend_tile, accY); have_pend = false; }  // judged by ITS group's thresholds, before they go
                 const ConstFloats gp = groups_k + (size_t)(q >> group_shift) * (sizeof(MfGroup) / 4);   // wave-uniform: scalar loads
                 MfGroup G;

@@ -557,13 +557,14 @@ template <int S>
 static void launch_intersect_mfma(rtgl_context *ctx, const SceneView &sc, uint32_t n0, uint32_t bounce)
 {
     const uint32_t gq = ctx->mf_group_quads, n_quads = ctx->n_mf_groups * gq;
-    uint32_t chunk_quads = ((uint32_t)ctx->opt_mf_chunk_quads + gq - 1) / gq * gq;             // whole groups per chunk
-    if (chunk_quads > kMfMaxChunkQuads) chunk_quads = kMfMaxChunkQuads / gq * gq;
+    uint32_t chunk_quads = std::min((uint32_t)ctx->opt_mf_chunk_quads, kMfMaxChunkQuads);
     const uint32_t est = estimate_rays(ctx, n0, bounce), rays_per_block = 4u * S * 32u;
     const uint32_t blocks_x = (est + rays_per_block - 1) / rays_per_block;
-    // late bounces have few rays: split the triangle range finer so that the launch still fills the chip several times over
-    while (chunk_quads > gq && (uint64_t)blocks_x * ((n_quads + chunk_quads - 1) / chunk_quads) < 4096u) chunk_quads = std::max(gq, chunk_quads / 2 / gq * gq);
-    dim3 grid(blocks_x, (n_quads + chunk_quads - 1) / chunk_quads);
+    // late bounces have few rays: split the triangle range finer (down to 8 quads, also inside a group) so that the launch
+    // still fills the chip and each block's serial share stays short
+    const uint32_t real_quads = std::min(n_quads, (ctx->n_tri_visits + (uint32_t)kMfQuadTris - 1) / (uint32_t)kMfQuadTris);
+    while (chunk_quads > 8u && (uint64_t)blocks_x * ((real_quads + chunk_quads - 1) / chunk_quads) < 4096u) chunk_quads /= 2u;
+    dim3 grid(blocks_x, (real_quads + chunk_quads - 1) / chunk_quads);
     if (ctx->opt_debug_skip_exact == 4 && !ctx->d_dbg_log) {
         (void)hipMalloc((void **)&ctx->d_dbg_log, (size_t)(2 + (2u << 22)) * 4);
         (void)hipMemsetAsync(ctx->d_dbg_log, 0, 8, ctx->stream);
