@@ -196,13 +196,13 @@ def main():
         if scan_launches == 0:            # a scene without triangles has no scan launches: describe the whole frame instead
             launches_per_frame, avg_launch_s, bytes_per_launch = 1, frame_ms / 1e3 / max(timed_frames, 1), alg["total"] * share
         flops_per_launch = cnt["triangle_tests"] * 36.0 * share / launches_per_frame   # 18 fma per edge-function triple
-        kname = {0: "pathtrace_mega_kernel", 1: "bounce_kernel", 2: "intersect_kernel", 3: "intersect_mfma_kernel"}[ctx.get_option("kernel_in_use")]
+        kname = {0: "pathtrace_mega_kernel", 1: "bounce_kernel", 2: "intersect_kernel", 3: "intersect_mfma_kernel", 4: "intersect_mfma_kernel"}[ctx.get_option("kernel_in_use")]
         if scan_launches == 0:
             kname = "whole frame (generate_rays + shade)"
         k = ctx.get_option("kernel_in_use")
         gtests = cnt["triangle_tests"] * share / launches_per_frame / avg_launch_s / 1e9
         tflops = flops_per_launch / avg_launch_s / 1e12
-        if k == 3:
+        if k in (3, 4):
             # bf16 matrix pipe for the conservative broad phase + fp32 VALU for thresholds/minima; both issue from the same
             # SIMD port and do not overlap (tools/mfma_bf16_valu_rate.hip), so the practical ceiling is the measured issue
             # floor of "one 32x32x16 MFMA + 5 v_min3 + 2 v_max3" = 22 ns per SIMD per 320 tests

@@ -184,6 +184,7 @@ struct rtgl_context {
     hipEvent_t counts_ev = nullptr; bool counts_pending = false, counts_valid = false;
     bool timing_this_frame = false; uint32_t timing_frame_counter = 0;
     int kernel_in_use = -1;                  // variant the last frame actually ran
+    bool wave_has_cand = false; int n_cus = 256;
     bool kernel_explicit = false;            // "kernel" was set through rtgl_set_option or RTGL_AMD_KERNEL
     uint32_t counts_n0 = 0, counts_len = 0;
     std::vector<uint32_t> est_counts;        // grid-size estimates for the next frame
@@ -239,6 +240,7 @@ extern "C" int rtgl_create_tiled(rtgl_context **out, int width, int height, int 
 #define CCHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { \
     ctx->error = std::string(#expr) + ": " + hipGetErrorString(e_); return bail(RTGL_ERR_DEVICE); } } while (0)
     CCHK(hipSetDevice(device));
+    { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) ctx->n_cus = prop.multiProcessorCount; }
     CCHK(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
     ctx->stream = ctx->own_stream;
     CCHK(hipEventCreate(&ctx->ev0));
@@ -252,7 +254,7 @@ extern "C" int rtgl_create_tiled(rtgl_context **out, int width, int height, int 
     CCHK(hipStreamSynchronize(ctx->stream));
 #undef CCHK
     // operational override of the default scan without touching the caller: RTGL_AMD_KERNEL=0..3 (rtgl_set_option still wins)
-    if (const char *k = getenv("RTGL_AMD_KERNEL")) { const int v = atoi(k); if (v >= RTGL_KERNEL_MEGA && v <= RTGL_KERNEL_WAVEFRONT_MFMA) { ctx->opt_kernel = v; ctx->kernel_explicit = true; } }
+    if (const char *k = getenv("RTGL_AMD_KERNEL")) { const int v = atoi(k); if (v >= RTGL_KERNEL_MEGA && v <= RTGL_KERNEL_WAVEFRONT_MFMA_SOLO) { ctx->opt_kernel = v; ctx->kernel_explicit = true; } }
     *out = ctx;
     return RTGL_OK;
 }
@@ -485,19 +487,21 @@ static int ensure_wave_buffers(rtgl_context *ctx, uint32_t n0, uint32_t max_boun
 {
     if (ctx->counts_capacity < max_bounce + 2) {
         if (ctx->d_counts) { HIPCHK(ctx, hipFree(ctx->d_counts)); ctx->d_counts = nullptr; }
-        HIPCHK(ctx, hipMalloc((void **)&ctx->d_counts, (size_t)(max_bounce + 2) * sizeof(uint32_t)));
+        HIPCHK(ctx, hipMalloc((void **)&ctx->d_counts, (size_t)(max_bounce + 2) * 2 * sizeof(uint32_t)));       // ray counts, then candidate counts (kernel 4)
         if (ctx->h_counts) { HIPCHK(ctx, hipHostFree(ctx->h_counts)); ctx->h_counts = nullptr; }
         HIPCHK(ctx, hipHostMalloc((void **)&ctx->h_counts, (size_t)(max_bounce + 2) * sizeof(uint32_t), hipHostMallocDefault));
         if (!ctx->counts_ev) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->counts_ev, hipEventDisableTiming));
         ctx->counts_capacity = max_bounce + 2; ctx->counts_pending = ctx->counts_valid = false; ctx->est_counts.clear();
     }
     const size_t local_px = (size_t)std::max(ctx->local_rows, 1) * ctx->width;
-    if (ctx->wave_capacity < n0 || (multi_sample && !ctx->wave_multi)) {
+    const bool want_cand = ctx->opt_kernel == RTGL_KERNEL_WAVEFRONT_MFMA_SOLO;
+    if (ctx->wave_capacity < n0 || (multi_sample && !ctx->wave_multi) || (want_cand && !ctx->wave_has_cand)) {
         if (ctx->d_wave) { HIPCHK(ctx, hipFree(ctx->d_wave)); ctx->d_wave = nullptr; }
         // per queue: 4 x 16 B + 4 B per ray; per-pixel state for u_samples > 1: 4 x 16 B
-        size_t q_bytes = (size_t)n0 * (68 + 8), bytes = 2 * q_bytes + 512 + (multi_sample ? local_px * 64 : 0);
+        const size_t cand_cap = ctx->opt_kernel == RTGL_KERNEL_WAVEFRONT_MFMA_SOLO ? std::max<size_t>((size_t)n0 * 16, (size_t)1 << 20) : 0;   // pairs of one bounce
+        size_t q_bytes = (size_t)n0 * (68 + 8), bytes = 2 * q_bytes + 1024 + cand_cap * 8 + (multi_sample ? local_px * 64 : 0);
         HIPCHK(ctx, hipMalloc(&ctx->d_wave, bytes));
-        ctx->wave_capacity = n0; ctx->wave_multi = multi_sample;
+        ctx->wave_capacity = n0; ctx->wave_multi = multi_sample; ctx->wave_has_cand = want_cand;
         uint8_t *p = (uint8_t *)ctx->d_wave;
         for (int q = 0; q < 2; ++q) {
             ctx->wb.q[q].a = (float4 *)p; p += (size_t)n0 * 16;
@@ -508,6 +512,8 @@ static int ensure_wave_buffers(rtgl_context *ctx, uint32_t n0, uint32_t max_boun
         for (int q = 0; q < 2; ++q) { ctx->wb.best[q] = (unsigned long long *)p; p += (size_t)n0 * 8; }
         for (int q = 0; q < 2; ++q) { ctx->wb.q[q].pixel = (uint32_t *)p; p += (size_t)n0 * 4; }
         p = (uint8_t *)(((uintptr_t)p + 255) & ~(uintptr_t)255);
+        ctx->wb.cand = (uint2 *)p; p += cand_cap * 8; ctx->wb.cand_capacity = (uint32_t)std::min<size_t>(cand_cap, 0xFFFFFFF0u);
+        p = (uint8_t *)(((uintptr_t)p + 255) & ~(uintptr_t)255);
         if (multi_sample) {
             ctx->wb.sums = (float4 *)p; p += local_px * 16;
             ctx->wb.cam_a = (float4 *)p; p += local_px * 16;
@@ -516,6 +522,7 @@ static int ensure_wave_buffers(rtgl_context *ctx, uint32_t n0, uint32_t max_boun
         } else ctx->wb.sums = ctx->wb.cam_a = ctx->wb.cam_b = nullptr, ctx->wb.pix_rng = nullptr;
     }
     ctx->wb.counts = ctx->d_counts;
+    ctx->wb.cand_counts = ctx->d_counts + ctx->counts_capacity;
     ctx->wb.group_bounds = ctx->d_group_bounds;
     return RTGL_OK;
 }
@@ -578,6 +585,31 @@ static void launch_intersect_mfma(rtgl_context *ctx, const SceneView &sc, uint32
         hipLaunchKernelGGL((intersect_mfma_kernel<S, false>), grid, dim3(256), 0, ctx->stream, sc, ctx->wb, mf, bounce, chunk_quads, ctx->d_counters, ctx->opt_debug_skip_exact);
 }
 
+// kernel 4: one block per CU (forced by the LDS request), persistent over the ray blocks of its triangle chunk
+static void launch_intersect_solo(rtgl_context *ctx, const SceneView &sc, uint32_t n0, uint32_t bounce)
+{
+    const uint32_t gq = ctx->mf_group_quads, n_quads = ctx->n_mf_groups * gq;
+    const uint32_t real_quads = std::min(n_quads, (ctx->n_tri_visits + (uint32_t)kMfQuadTris - 1) / (uint32_t)kMfQuadTris);
+    const uint32_t chunk_quads = std::min(32u, std::max(real_quads, 1u));                       // 128 KB of A tiles in LDS
+    const uint32_t chunks = (real_quads + chunk_quads - 1) / chunk_quads;
+    const uint32_t est = estimate_rays(ctx, n0, bounce), blocks_x_all = (est + 255u) / 256u;
+    const uint32_t blocks_x = std::max(1u, std::min(blocks_x_all, ((uint32_t)ctx->n_cus + chunks - 1) / chunks));
+    const size_t lds = std::max<size_t>((size_t)chunk_quads * kMfQuadTiles * 1024, 96 * 1024);   // > half of the CU's LDS with the static queue: one block per CU
+    MfView mf{ctx->d_mf_groups, ctx->n_mf_groups, gq, n_quads, ctx->d_mf_A, ctx->d_dbg_log, ctx->d_mf_order};
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&intersect_mfma_kernel<2, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&intersect_mfma_kernel<2, true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024);
+        attr_set = true;
+    }
+    dim3 grid(blocks_x, chunks);
+    if (ctx->opt_counters)
+        hipLaunchKernelGGL((intersect_mfma_kernel<2, true, false, true>), grid, dim3(256), lds, ctx->stream, sc, ctx->wb, mf, bounce, chunk_quads, ctx->d_counters, ctx->opt_debug_skip_exact);
+    else
+        hipLaunchKernelGGL((intersect_mfma_kernel<2, false, false, true>), grid, dim3(256), lds, ctx->stream, sc, ctx->wb, mf, bounce, chunk_quads, ctx->d_counters, ctx->opt_debug_skip_exact);
+    hipLaunchKernelGGL(narrow_phase_kernel, dim3(2048), dim3(256), 0, ctx->stream, sc, ctx->wb, bounce);
+}
+
 static int launch_wavefront(rtgl_context *ctx, const SceneView &sc, const FrameParams &P, const ImageView &im, uint32_t n0, uint4 *rng_out)
 {
     const dim3 gen_grid((n0 + 255) / 256);
@@ -588,13 +620,17 @@ static int launch_wavefront(rtgl_context *ctx, const SceneView &sc, const FrameP
         else ctx->est_counts.clear();
     }
     for (uint32_t s = 0; s < P.samples; ++s) {
-        HIPCHK(ctx, hipMemsetAsync(ctx->d_counts, 0, (size_t)(P.max_bounce + 2) * sizeof(uint32_t), ctx->stream));
+        HIPCHK(ctx, hipMemsetAsync(ctx->d_counts, 0, (size_t)ctx->counts_capacity * 2 * sizeof(uint32_t), ctx->stream));
         hipLaunchKernelGGL(generate_rays_kernel, gen_grid, dim3(256), 0, ctx->stream, P, im, ctx->wb, s, n0,
                            ctx->opt_counters ? ctx->d_counters : (Counters *)nullptr);
         for (uint32_t b = 0; b < P.max_bounce; ++b) {
             const int key = ctx->opt_wf_mode * 10 + ctx->opt_wf_rays;
-            if (ctx->opt_kernel == RTGL_KERNEL_WAVEFRONT_SPLIT || ctx->opt_kernel == RTGL_KERNEL_WAVEFRONT_MFMA) {
-                if (sc.n_tri_visits > 0 && ctx->opt_kernel == RTGL_KERNEL_WAVEFRONT_MFMA) {
+            if (ctx->opt_kernel == RTGL_KERNEL_WAVEFRONT_SPLIT || ctx->opt_kernel == RTGL_KERNEL_WAVEFRONT_MFMA || ctx->opt_kernel == RTGL_KERNEL_WAVEFRONT_MFMA_SOLO) {
+                if (sc.n_tri_visits > 0 && ctx->opt_kernel == RTGL_KERNEL_WAVEFRONT_MFMA_SOLO) {
+                    kev_mark(ctx);
+                    launch_intersect_solo(ctx, sc, n0, b);
+                    kev_mark(ctx);
+                } else if (sc.n_tri_visits > 0 && ctx->opt_kernel == RTGL_KERNEL_WAVEFRONT_MFMA) {
                     kev_mark(ctx);
                     launch_intersect_mfma<2>(ctx, sc, n0, b);
                     kev_mark(ctx);
@@ -892,7 +928,7 @@ extern "C" int rtgl_set_option(rtgl_context *ctx, const char *key, int value)
     ENTER(ctx);
     if (!key) return fail(ctx, RTGL_ERR_INVALID, "key is NULL");
     if (!strcmp(key, "kernel")) {
-        if (value < RTGL_KERNEL_MEGA || value > RTGL_KERNEL_WAVEFRONT_MFMA)
+        if (value < RTGL_KERNEL_MEGA || value > RTGL_KERNEL_WAVEFRONT_MFMA_SOLO)
             return fail(ctx, RTGL_ERR_INVALID, "unknown kernel variant");
         ctx->opt_kernel = value; ctx->kernel_explicit = true;
     } else if (!strcmp(key, "wf_rays")) {

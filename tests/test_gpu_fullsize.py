@@ -52,11 +52,11 @@ def test_c2_counters(c2_reference_image, rt):
     assert np.isfinite(img).all() and (img[..., 3] == 1.0).all()
 
 
-@pytest.mark.parametrize("variant", [(0, 0, 1, 1024), (1, 1, 2, 1024), (2, 0, 2, 512), (2, 1, 8, 256), (2, 1, 1, 2560), (3, 4, 2, 64), (3, 1, 2, 16), (3, 64, 2, 32)])
+@pytest.mark.parametrize("variant", [(0, 0, 1, 1024), (1, 1, 2, 1024), (2, 0, 2, 512), (2, 1, 8, 256), (2, 1, 1, 2560), (3, 4, 2, 64), (3, 1, 2, 16), (3, 64, 2, 32), (4, 32, 2, 64), (4, 4, 2, 64)])
 def test_c2_all_kernel_variants_identical(variant, c2_reference_image, rt):
     base = c2_reference_image[0]
-    if variant[0] == 3:
-        opts = (("kernel", 3), ("mf_group_quads", variant[1]), ("mf_sets", variant[2]), ("mf_chunk_quads", variant[3]))
+    if variant[0] in (3, 4):
+        opts = (("kernel", variant[0]), ("mf_group_quads", variant[1]), ("mf_sets", variant[2]), ("mf_chunk_quads", variant[3]))
     else:
         opts = (("kernel", variant[0]), ("wf_mode", variant[1]), ("wf_rays", variant[2]), ("wf_chunk", variant[3]))
     img = render(rt, "C2", frames=2, options=opts)[0]

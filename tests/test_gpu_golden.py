@@ -44,6 +44,14 @@ def test_matrix_core_broad_phase_small_chunks_matches_reference_shader_output(pa
 
 
 @pytest.mark.parametrize("path", CASE_FILES, ids=lambda p: os.path.basename(p)[:-4])
+def test_one_wave_per_simd_scan_matches_reference_shader_output(path, rt):
+    """kernel 4: persistent blocks, A tiles in LDS, interleaved examination, separate narrow phase -- every golden case."""
+    meta, scene, frames, expected = load_case(path, rt)
+    img = render_case(rt, meta, scene, frames, options=(("kernel", 4),))
+    assert (img.view(np.uint32) == expected.view(np.uint32)).all()
+
+
+@pytest.mark.parametrize("path", CASE_FILES, ids=lambda p: os.path.basename(p)[:-4])
 def test_fp32_scan_kernel_matches_reference_shader_output(path, rt):
     """kernel 2: fp32 VALU filter + exact test (the variant without matrix cores) -- every golden case, bit for bit."""
     meta, scene, frames, expected = load_case(path, rt)
