@@ -213,7 +213,7 @@ __device__ __forceinline__ void mf_flush(const MfFlushArgs &f, const uint32_t *q
             const uint32_t at = atomicAdd(f.dbg_log, 1u);
             if (at < (1u << 22)) { f.dbg_log[2 + 2 * at] = f.wave_slot0 + (e >> 16); f.dbg_log[3 + 2 * at] = pos; }
         }
-        if (pos < f.v_chunk_end && (f.debug_skip_exact == 0 || f.debug_skip_exact == 4)) {
+        if (pos < f.v_chunk_end && (f.debug_skip_exact == 0 || f.debug_skip_exact >= 4)) {
             const uint32_t slot = f.wave_slot0 + (e >> 16), v = f.order[pos];
             const float4 a = f.ray_a[slot], b = f.ray_b[slot];
             TriRay tr; tr.o = mk(a.x, a.y, a.z); tr.d = mk(a.w, b.x, b.y); tr.cv = cross3(tr.d, tr.o); tr.ncv = tr.nd = 0.0f;
@@ -338,6 +338,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(kSolo 
         };
         bf16x8 B[S];
         float thresh[S];
+#ifdef MF_CHECKSUM
+        unsigned long long chk = 0ull, chk_any = 0ull;
+#endif
         f32x16 accX[S], accY[S];
         uint32_t pend_tile = 0u; bool have_pend = false;                  // wave-uniform: the tile whose products wait in accY
         const f32x16 zero = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
@@ -348,6 +351,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(kSolo 
             // A finite threshold means finite operands and edge values below 2^7 * 1e30 in magnitude, hence finite
             // minima: max-of-minima is then exactly "some triangle of this lane survives".  A NaN threshold passes all.
             const float mx = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(mn[0], mn[1]), mn[2]), mn[3]), mn[4]);   // two v_max3
+#ifdef MF_CHECKSUM          // diagnostics build: order-independent checksum of every examined minimum (debug_skip_exact = 5 prints it)
+#pragma unroll
+            for (int u = 0; u < 5; ++u) chk += (unsigned long long)__float_as_uint(mn[u]) * (0x9E3779B97F4A7C15ull + 2ull * (unsigned)u);
+            chk_any += (unsigned long long)(!(mx <= thresh[s]));
+#endif
             return !(mx <= thresh[s]);
         };
         // rare path: some lane has a survivor in `tile` -> per (ray set, triangle) ballots, survivors into the wave's LDS queue
@@ -482,6 +490,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(kSolo 
         }
         if (have_pend) examine(pend_tile, accY);
         flush();
+#ifdef MF_CHECKSUM
+        if (mf.dbg_log) { atomicAdd(reinterpret_cast<unsigned long long *>(mf.dbg_log) + 1, chk); atomicAdd(reinterpret_cast<unsigned long long *>(mf.dbg_log) + 2, chk_any); }
+#endif
         const uint32_t n_cand = (lane == 0) ? n_total : 0u;
         c_cand_total += n_cand;
     }

@@ -572,17 +572,19 @@ static void launch_intersect_mfma(rtgl_context *ctx, const SceneView &sc, uint32
     const uint32_t real_quads = std::min(n_quads, (ctx->n_tri_visits + (uint32_t)kMfQuadTris - 1) / (uint32_t)kMfQuadTris);
     while (chunk_quads > 8u && (uint64_t)blocks_x * ((real_quads + chunk_quads - 1) / chunk_quads) < 4096u) chunk_quads /= 2u;
     dim3 grid(blocks_x, (real_quads + chunk_quads - 1) / chunk_quads);
-    if (ctx->opt_debug_skip_exact == 4 && !ctx->d_dbg_log) {
+    if ((ctx->opt_debug_skip_exact == 4 || ctx->opt_debug_skip_exact == 5) && !ctx->d_dbg_log) {
         (void)hipMalloc((void **)&ctx->d_dbg_log, (size_t)(2 + (2u << 22)) * 4);
-        (void)hipMemsetAsync(ctx->d_dbg_log, 0, 8, ctx->stream);
+        (void)hipMemsetAsync(ctx->d_dbg_log, 0, 32, ctx->stream);
     }
     MfView mf{ctx->d_mf_groups, ctx->n_mf_groups, gq, n_quads, ctx->d_mf_A, ctx->d_dbg_log, ctx->d_mf_order};
+    // diagnostics: RTGL_DEBUG_LDS_PAD=bytes of unused dynamic LDS per block limits the blocks per CU (60000 -> one wave per SIMD)
+    const size_t lds_pad = getenv("RTGL_DEBUG_LDS_PAD") ? (size_t)atoi(getenv("RTGL_DEBUG_LDS_PAD")) : 0;
     if (ctx->opt_debug_skip_exact == 3)
         hipLaunchKernelGGL((intersect_mfma_kernel<2, true, true>), dim3((est + 255) / 256, grid.y), dim3(256), 0, ctx->stream, sc, ctx->wb, mf, bounce, chunk_quads, ctx->d_counters, 0);
     else if (ctx->opt_counters)
-        hipLaunchKernelGGL((intersect_mfma_kernel<S, true>), grid, dim3(256), 0, ctx->stream, sc, ctx->wb, mf, bounce, chunk_quads, ctx->d_counters, ctx->opt_debug_skip_exact);
+        hipLaunchKernelGGL((intersect_mfma_kernel<S, true>), grid, dim3(256), lds_pad, ctx->stream, sc, ctx->wb, mf, bounce, chunk_quads, ctx->d_counters, ctx->opt_debug_skip_exact);
     else
-        hipLaunchKernelGGL((intersect_mfma_kernel<S, false>), grid, dim3(256), 0, ctx->stream, sc, ctx->wb, mf, bounce, chunk_quads, ctx->d_counters, ctx->opt_debug_skip_exact);
+        hipLaunchKernelGGL((intersect_mfma_kernel<S, false>), grid, dim3(256), lds_pad, ctx->stream, sc, ctx->wb, mf, bounce, chunk_quads, ctx->d_counters, ctx->opt_debug_skip_exact);
 }
 
 // kernel 4: one block per CU (forced by the LDS request), persistent over the ray blocks of its triangle chunk
@@ -898,6 +900,12 @@ extern "C" int rtgl_get_counters(rtgl_context *ctx, rtgl_counters *out)
         HIPCHK(ctx, hipMemcpy(h.data(), ctx->d_dbg_log, h.size() * 4, hipMemcpyDeviceToHost));
         if (FILE *f = fopen(getenv("RTGL_DEBUG_DUMP"), "ab")) { const uint32_t n = std::min(h[0], 1u << 22); fwrite(&n, 4, 1, f); fwrite(h.data() + 2, 8, n, f); fclose(f); }
         HIPCHK(ctx, hipMemset(ctx->d_dbg_log, 0, 8));
+    }
+    if (ctx->opt_debug_skip_exact == 5 && ctx->d_dbg_log) {      // checksum of every examined minimum (builds with -DMF_CHECKSUM)
+        unsigned long long h[4];
+        HIPCHK(ctx, hipMemcpy(h, ctx->d_dbg_log, sizeof h, hipMemcpyDeviceToHost));
+        fprintf(stderr, "rtgl checksum: minima %016llx  lanes-with-survivor %llu\n", h[1], h[2]);
+        HIPCHK(ctx, hipMemset(ctx->d_dbg_log, 0, 32));
     }
     if (ctx->opt_debug_skip_exact == 3) {          // kernel-3 verification log: pairs the broad phase rejected but the exact test accepts
         static MfVerifyLog log;
