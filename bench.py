@@ -239,6 +239,21 @@ def main():
             "compute": compute,
             "counters_per_frame": cnt,
         }
+        if world == 1 and ctx.get_option("kernel_in_use") == 4 and args.kernel is None:
+            # not part of `value`: the same frames with the three-waves-per-SIMD scan (kernel 3), the fast variant that is NOT the
+            # default because of the rare cross-wave fault described in DESIGN.md section 5
+            ctx.set_option("kernel", 3)
+            ctx.set_option("kernel_timing", 0)
+            for p in timed[:3]:
+                ctx.render(p, sync=False)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for p in timed:
+                ctx.render(p, sync=False)
+            torch.cuda.synchronize()
+            out["fast_mode"] = {"kernel": 3, "value": paths / (time.perf_counter() - t1) / 1e6, "unit": "Mpaths/s",
+                                "note": "opt-in (RTGL_AMD_KERNEL=3): three waves per SIMD; bit-identical in every soak of this build, but see DESIGN.md section 5"}
+            ctx.set_option("kernel", 4)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(rt, scene, timed[0], W, H, args.cpu_rows)
         print(json.dumps(out), flush=True)

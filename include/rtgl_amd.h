@@ -74,8 +74,9 @@ enum {
     RTGL_KERNEL_MEGA = 0,            /* one launch per frame, one lane per pixel, whole path in registers */
     RTGL_KERNEL_WAVEFRONT = 1,       /* one fused launch per bounce over the compacted ray queue */
     RTGL_KERNEL_WAVEFRONT_SPLIT = 2, /* per bounce: intersect (ray blocks x triangle chunks, fp32 VALU filter) + shade */
-    RTGL_KERNEL_WAVEFRONT_MFMA = 3,  /* as 2, with a conservative bf16 matrix-core broad phase in front of the exact test; default */
-    RTGL_KERNEL_WAVEFRONT_MFMA_SOLO = 4 /* as 3 with one wave per SIMD: persistent blocks, A tiles in LDS, examination interleaved with the
+    RTGL_KERNEL_WAVEFRONT_MFMA = 3,  /* as 2, with a conservative bf16 matrix-core broad phase in front of the exact test, 3 waves per SIMD: the
+                                      * fastest variant, but see DESIGN.md section 5 (a rare cross-wave fault; opt-in) */
+    RTGL_KERNEL_WAVEFRONT_MFMA_SOLO = 4 /* default: as 3 with one wave per SIMD: persistent blocks, A tiles in LDS, examination interleaved with the
                                          * matrix instructions, exact tests in a separate narrow-phase kernel */
 };
 

@@ -250,7 +250,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(kSolo 
     // in the middle of a group: the group's origin and bounds are set up at the first quad of every chunk as well)
     // per-wave survivor queue, entry = (ray in wave) << 16 | triangle offset in chunk.  Half a loop step (2 tiles x S ray sets
     // x 5 triangles x 64 lanes) can add at most kStepMax entries, and the queue is drained between half steps once it holds kDrain
-    constexpr uint32_t kStepMax = (kMfQuadTiles / 2) * S * 5 * 64, kDrain = 192, kQueue = kStepMax + kDrain;
+    constexpr uint32_t kStepMax = (kSolo ? 1 : kMfQuadTiles / 2) * S * 5 * 64, kDrain = 192, kQueue = kStepMax + kDrain;   // kSolo drains after every tile
     __shared__ uint32_t lds_queue[4 * kQueue];
     const uint32_t n_rays = wb.counts[bounce];
     const RayQueue qin = (bounce & 1u) ? wb.q[1] : wb.q[0];
@@ -423,16 +423,17 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(kSolo 
         auto stage = [&](const uint4 &a, f32x16 (&nxt)[S], bool examine_pending, uint32_t pending_tile, f32x16 (&pend)[S]) {
             const bf16x8 Aop = __builtin_bit_cast(bf16x8, a);
             if (kSolo) {
-                // one wave per SIMD: the examination of one ray set of the pending tile rides behind each product
-                float mn[S][5];
-                bool any_lane = false;
+                // one wave per SIMD: the S products, then the pending tile; no cross-wave effect to keep clear of, the compiler's own
+                // wait states for the register dependences are all that is needed (and its scheduler may mix the two).  VALU reads of
+                // MFMA-written registers are slow next to an in-flight MFMA of the same wave: ~115 cycles per product with S = 4,
+                // 127 with S = 2 and one ray set examined behind each product.
 #pragma unroll
-                for (int s = 0; s < S; ++s) {
-                    nxt[s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Aop, B[s], zero, 0, 0, 0);
-                    asm volatile("" : "+v"(accX[0]), "+v"(accX[S - 1]), "+v"(accY[0]), "+v"(accY[S - 1]));
-                    if (examine_pending) any_lane |= minima(s, pend[s], mn[s]);
-                }
-                if (examine_pending && __builtin_amdgcn_ballot_w64(any_lane) != 0ull) park(pending_tile, pend, mn);
+                for (int s = 0; s < S; ++s) nxt[s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Aop, B[s], zero, 0, 0, 0);
+                // (pinning all accumulators so that the products stay back to back was measured: 240 instead of 254 Mpaths/s; the
+                // scheduler's own interleaving is kept)
+                asm volatile("" : "+v"(accX[0]), "+v"(accX[S - 1]), "+v"(accY[0]), "+v"(accY[S - 1]));
+                if (examine_pending) examine(pending_tile, pend);
+                if (qn >= kDrain) flush();
                 return;
             }
 #if MF_ISSUE_GAP >= 0

@@ -193,7 +193,7 @@ struct rtgl_context {
     bool tris_dirty = false, visits_dirty = false;
     FrameParams params{};
     bool have_params = false;
-    int opt_kernel = RTGL_KERNEL_WAVEFRONT_MFMA, opt_rng_state = 0, opt_counters = 0, opt_kernel_timing = 0, opt_wf_rays = 4, opt_wf_mode = kLds, opt_wf_chunk = 256, opt_wf_early = 0, opt_wf_packed = 0, opt_mf_sets = 2, opt_mf_chunk_quads = 64, opt_mf_group_quads = 32, opt_debug_skip_exact = 0;
+    int opt_kernel = RTGL_KERNEL_WAVEFRONT_MFMA_SOLO, opt_rng_state = 0, opt_counters = 0, opt_kernel_timing = 0, opt_wf_rays = 4, opt_wf_mode = kLds, opt_wf_chunk = 256, opt_wf_early = 0, opt_wf_packed = 0, opt_mf_sets = 2, opt_mf_chunk_quads = 64, opt_mf_group_quads = 32, opt_debug_skip_exact = 0;
 };
 
 static int fail(rtgl_context *ctx, int code, const std::string &msg)
@@ -498,7 +498,7 @@ static int ensure_wave_buffers(rtgl_context *ctx, uint32_t n0, uint32_t max_boun
     if (ctx->wave_capacity < n0 || (multi_sample && !ctx->wave_multi) || (want_cand && !ctx->wave_has_cand)) {
         if (ctx->d_wave) { HIPCHK(ctx, hipFree(ctx->d_wave)); ctx->d_wave = nullptr; }
         // per queue: 4 x 16 B + 4 B per ray; per-pixel state for u_samples > 1: 4 x 16 B
-        const size_t cand_cap = ctx->opt_kernel == RTGL_KERNEL_WAVEFRONT_MFMA_SOLO ? std::max<size_t>((size_t)n0 * 16, (size_t)1 << 20) : 0;   // pairs of one bounce
+        const size_t cand_cap = ctx->opt_kernel == RTGL_KERNEL_WAVEFRONT_MFMA_SOLO ? std::max<size_t>((size_t)n0 * 32, (size_t)1 << 20) : 0;   // pairs of one bounce (8 B each; overflow is tested in place)
         size_t q_bytes = (size_t)n0 * (68 + 8), bytes = 2 * q_bytes + 1024 + cand_cap * 8 + (multi_sample ? local_px * 64 : 0);
         HIPCHK(ctx, hipMalloc(&ctx->d_wave, bytes));
         ctx->wave_capacity = n0; ctx->wave_multi = multi_sample; ctx->wave_has_cand = want_cand;
@@ -594,21 +594,23 @@ static void launch_intersect_solo(rtgl_context *ctx, const SceneView &sc, uint32
     const uint32_t real_quads = std::min(n_quads, (ctx->n_tri_visits + (uint32_t)kMfQuadTris - 1) / (uint32_t)kMfQuadTris);
     const uint32_t chunk_quads = std::min(32u, std::max(real_quads, 1u));                       // 128 KB of A tiles in LDS
     const uint32_t chunks = (real_quads + chunk_quads - 1) / chunk_quads;
-    const uint32_t est = estimate_rays(ctx, n0, bounce), blocks_x_all = (est + 255u) / 256u;
-    const uint32_t blocks_x = std::max(1u, std::min(blocks_x_all, ((uint32_t)ctx->n_cus + chunks - 1) / chunks));
+    constexpr int kSoloSets = 4;                                                                  // 32-ray sets per wave: 512 rays per block
+    const uint32_t est = estimate_rays(ctx, n0, bounce), blocks_x_all = (est + 128u * kSoloSets - 1u) / (128u * kSoloSets);
+    // one block per CU in total: with more, the surplus runs as a second, mostly empty round
+    const uint32_t blocks_x = std::max(1u, std::min(blocks_x_all, (uint32_t)ctx->n_cus / chunks));
     const size_t lds = std::max<size_t>((size_t)chunk_quads * kMfQuadTiles * 1024, 96 * 1024);   // > half of the CU's LDS with the static queue: one block per CU
     MfView mf{ctx->d_mf_groups, ctx->n_mf_groups, gq, n_quads, ctx->d_mf_A, ctx->d_dbg_log, ctx->d_mf_order};
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&intersect_mfma_kernel<2, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&intersect_mfma_kernel<2, true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&intersect_mfma_kernel<kSoloSets, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&intersect_mfma_kernel<kSoloSets, true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024);
         attr_set = true;
     }
     dim3 grid(blocks_x, chunks);
     if (ctx->opt_counters)
-        hipLaunchKernelGGL((intersect_mfma_kernel<2, true, false, true>), grid, dim3(256), lds, ctx->stream, sc, ctx->wb, mf, bounce, chunk_quads, ctx->d_counters, ctx->opt_debug_skip_exact);
+        hipLaunchKernelGGL((intersect_mfma_kernel<kSoloSets, true, false, true>), grid, dim3(256), lds, ctx->stream, sc, ctx->wb, mf, bounce, chunk_quads, ctx->d_counters, ctx->opt_debug_skip_exact);
     else
-        hipLaunchKernelGGL((intersect_mfma_kernel<2, false, false, true>), grid, dim3(256), lds, ctx->stream, sc, ctx->wb, mf, bounce, chunk_quads, ctx->d_counters, ctx->opt_debug_skip_exact);
+        hipLaunchKernelGGL((intersect_mfma_kernel<kSoloSets, false, false, true>), grid, dim3(256), lds, ctx->stream, sc, ctx->wb, mf, bounce, chunk_quads, ctx->d_counters, ctx->opt_debug_skip_exact);
     hipLaunchKernelGGL(narrow_phase_kernel, dim3(2048), dim3(256), 0, ctx->stream, sc, ctx->wb, bounce);
 }
 

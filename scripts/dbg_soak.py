@@ -14,7 +14,8 @@ def run(opts):
     for f in range(1, N + 1):
         ctx.render(cfg["params"]().replace(frames=f, random=g.rand())); cands.append(ctx.counters()["candidates"])
     img = ctx.read_image(); ctx.close(); return cands, img
-c1, i1 = run((("kernel", 3),)); c2, i2 = run((("kernel", 3),)); c3, i3 = run((("kernel", 3), ("mf_group_quads", 1))); _, ref = run((("kernel", 2),))
+K = int(os.environ.get("KERNEL", "3"))
+c1, i1 = run((("kernel", K),)); c2, i2 = run((("kernel", K),)); c3, i3 = run((("kernel", K), ("mf_group_quads", 1))); _, ref = run((("kernel", 2),))
 print("frames", N, "survivor counts repeat:", c1 == c2, "sum", sum(c1))
-print("kernel 3 run 1 vs run 2 differing pixels:", int((i1.view(np.uint32) != i2.view(np.uint32)).any(axis=2).sum()))
-print("kernel 3 vs kernel 2 differing pixels:", int((i1.view(np.uint32) != ref.view(np.uint32)).any(axis=2).sum()), "(Q=1:", int((i3.view(np.uint32) != ref.view(np.uint32)).any(axis=2).sum()), ")")
+print("kernel", K, "run 1 vs run 2 differing pixels:", int((i1.view(np.uint32) != i2.view(np.uint32)).any(axis=2).sum()))
+print("kernel", K, "vs kernel 2 differing pixels:", int((i1.view(np.uint32) != ref.view(np.uint32)).any(axis=2).sum()), "(Q=1:", int((i3.view(np.uint32) != ref.view(np.uint32)).any(axis=2).sum()), ")")

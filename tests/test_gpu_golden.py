@@ -27,7 +27,7 @@ def render_case(rt, meta, scene, frames, options=()):
 
 @pytest.mark.parametrize("path", CASE_FILES, ids=lambda p: os.path.basename(p)[:-4])
 def test_default_kernel_matches_reference_shader_output(path, rt):
-    """library defaults (kernel 3, 4 quads per group, 64-quad chunks) -- every golden case, bit for bit."""
+    """library defaults (kernel 4: one wave per SIMD, 32 quads per group) -- every golden case, bit for bit."""
     meta, scene, frames, expected = load_case(path, rt)
     img = render_case(rt, meta, scene, frames)
     neq = (img.view(np.uint32) != expected.view(np.uint32)).any(axis=2)

@@ -109,7 +109,7 @@ def test_triangle_free_scene_defaults_to_the_megakernel_and_explicit_choice_wins
     scene, p = sc.scene_c1(), sc.params_c1().replace(frames=1, random=sc.GlibcRand(0).rand())
     want = np.zeros((64, 64, 4), np.float32)
     oracle.render(scene, p, want, threads=4)
-    for explicit, expect in ((None, 0), (3, 3), (2, 2)):
+    for explicit, expect in ((None, 0), (4, 4), (3, 3), (2, 2)):
         ctx = rt.host.Context(64, 64)
         if explicit is not None:
             ctx.set_option("kernel", explicit)
@@ -122,5 +122,5 @@ def test_triangle_free_scene_defaults_to_the_megakernel_and_explicit_choice_wins
     ctx = rt.host.Context(64, 64)
     ctx.upload_scene(mesh)
     ctx.render(sc.params_c2().replace(frames=1, random=1))
-    assert ctx.get_option("kernel_in_use") == 3
+    assert ctx.get_option("kernel_in_use") == 4
     ctx.close()
