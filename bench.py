@@ -85,6 +85,7 @@ def main():
     ap.add_argument("--strip-rows", type=int, default=8, help="rows per interleaved strip (multiple of 8); 8 balances the ranks to +-3%% at N = 8, 16 to +-6%%")
     ap.add_argument("--timing-period", type=int, default=None, help="frames between kernel-timed frames (default: 1 at N = 1, 4 for N > 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fast-mode", action="store_true", help="skip the extra (unreported in `value`) measurement of the kernel-3 fast variant")
     ap.add_argument("--sync-each-frame", action="store_true", help="diagnostic: host waits for every frame")
     ap.add_argument("--no-kernel-timing", action="store_true", help="diagnostic: no HIP events around the scan launches")
     ap.add_argument("--cpu-rows", type=int, default=256)
@@ -239,7 +240,7 @@ def main():
             "compute": compute,
             "counters_per_frame": cnt,
         }
-        if world == 1 and ctx.get_option("kernel_in_use") == 4 and args.kernel is None:
+        if world == 1 and ctx.get_option("kernel_in_use") == 4 and args.kernel is None and not args.no_fast_mode:
             # not part of `value`: the same frames with the three-waves-per-SIMD scan (kernel 3), the fast variant that is NOT the
             # default because of the rare cross-wave fault described in DESIGN.md section 5
             ctx.set_option("kernel", 3)
