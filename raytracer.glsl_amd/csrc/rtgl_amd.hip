@@ -513,6 +513,8 @@ static int ensure_wave_buffers(rtgl_context *ctx, uint32_t n0, uint32_t max_boun
         for (int q = 0; q < 2; ++q) { ctx->wb.q[q].pixel = (uint32_t *)p; p += (size_t)n0 * 4; }
         p = (uint8_t *)(((uintptr_t)p + 255) & ~(uintptr_t)255);
         ctx->wb.cand = (uint2 *)p; p += cand_cap * 8; ctx->wb.cand_capacity = (uint32_t)std::min<size_t>(cand_cap, 0xFFFFFFF0u);
+        // diagnostics: RTGL_DEBUG_CAND_CAP=n pretends the buffer holds n pairs only, so that the in-place fallback of the scan runs
+        if (const char *cc = getenv("RTGL_DEBUG_CAND_CAP")) ctx->wb.cand_capacity = std::min<uint32_t>(ctx->wb.cand_capacity, (uint32_t)atoi(cc));
         p = (uint8_t *)(((uintptr_t)p + 255) & ~(uintptr_t)255);
         if (multi_sample) {
             ctx->wb.sums = (float4 *)p; p += local_px * 16;

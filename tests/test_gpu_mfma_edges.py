@@ -79,3 +79,15 @@ def test_needles_and_mixed_scales_in_one_group(rt, oracle, variant):
     v[idx[30:], 0, :3] += rng.normal(size=(30, 3)).astype(np.float32) * 40.0                      # long needles
     r = run_both(rt, oracle, scene_with(rt, v), sc.params_c2(), 120, 72, frames=2, variant=variant)
     assert_bit_exact(r, 120, 72)
+
+
+def test_candidate_buffer_overflow_falls_back_to_in_place_exact_tests(rt, oracle, monkeypatch):
+    """kernel 4 appends survivors to a global buffer for the narrow-phase kernel; pairs that do not fit are tested inside the scan.
+    With the buffer clamped to 1000 pairs almost everything takes that path: the result must not change."""
+    monkeypatch.setenv("RTGL_DEBUG_CAND_CAP", "1000")
+    sc = rt.scenes
+    patch = sc.grid_mesh(4, 3, x0=-12.0, x1=12.0, y0=-10.0, y1=4.0, amp=0.0).reshape(-1, 4)
+    v = np.concatenate([patch] * 20 + [sc.grid_mesh(20, 10).reshape(-1, 4)])
+    r = run_both(rt, oracle, scene_with(rt, v), sc.params_c2(), 136, 72, frames=2, variant=(4, 4, 2))
+    assert_bit_exact(r, 136, 72)
+    assert r["cnt_g"]["candidates"] > 20000
