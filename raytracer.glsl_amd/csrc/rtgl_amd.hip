@@ -594,9 +594,13 @@ static void launch_intersect_solo(rtgl_context *ctx, const SceneView &sc, uint32
 {
     const uint32_t gq = ctx->mf_group_quads, n_quads = ctx->n_mf_groups * gq;
     const uint32_t real_quads = std::min(n_quads, (ctx->n_tri_visits + (uint32_t)kMfQuadTris - 1) / (uint32_t)kMfQuadTris);
-    const uint32_t chunk_quads = std::min(32u, std::max(real_quads, 1u));                       // 128 KB of A tiles in LDS
+#ifndef RTGL_SOLO_SETS       // measured on C2: 3 sets 237, 4 sets 255, 5 sets 254, 6 sets 230 (spills), 8 sets 11 Mpaths/s
+#define RTGL_SOLO_SETS 4
+#define RTGL_SOLO_CHUNK 32u
+#endif
+    const uint32_t chunk_quads = std::min(RTGL_SOLO_CHUNK, std::max(real_quads, 1u));             // <= 128 KB of A tiles in LDS
     const uint32_t chunks = (real_quads + chunk_quads - 1) / chunk_quads;
-    constexpr int kSoloSets = 4;                                                                  // 32-ray sets per wave: 512 rays per block
+    constexpr int kSoloSets = RTGL_SOLO_SETS;                                                     // 32-ray sets per wave: 128 x sets rays per block
     const uint32_t est = estimate_rays(ctx, n0, bounce), blocks_x_all = (est + 128u * kSoloSets - 1u) / (128u * kSoloSets);
     // one block per CU in total: with more, the surplus runs as a second, mostly empty round
     const uint32_t blocks_x = std::max(1u, std::min(blocks_x_all, (uint32_t)ctx->n_cus / chunks));
@@ -604,8 +608,14 @@ static void launch_intersect_solo(rtgl_context *ctx, const SceneView &sc, uint32
     MfView mf{ctx->d_mf_groups, ctx->n_mf_groups, gq, n_quads, ctx->d_mf_A, ctx->d_dbg_log, ctx->d_mf_order};
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&intersect_mfma_kernel<kSoloSets, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&intersect_mfma_kernel<kSoloSets, true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024);
+        // allow the whole LDS of a CU (160 KB) minus the kernel's static share as dynamic shared memory
+        for (const void *fn : {reinterpret_cast<const void *>(&intersect_mfma_kernel<kSoloSets, false, false, true>),
+                               reinterpret_cast<const void *>(&intersect_mfma_kernel<kSoloSets, true, false, true>)}) {
+            hipFuncAttributes fattr;
+            if (hipFuncGetAttributes(&fattr, fn) == hipSuccess)
+                (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024 - fattr.sharedSizeBytes));
+        }
+        (void)hipGetLastError();
         attr_set = true;
     }
     dim3 grid(blocks_x, chunks);
