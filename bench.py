@@ -197,7 +197,7 @@ def main():
         if scan_launches == 0:            # a scene without triangles has no scan launches: describe the whole frame instead
             launches_per_frame, avg_launch_s, bytes_per_launch = 1, frame_ms / 1e3 / max(timed_frames, 1), alg["total"] * share
         flops_per_launch = cnt["triangle_tests"] * 36.0 * share / launches_per_frame   # 18 fma per edge-function triple
-        kname = {0: "pathtrace_mega_kernel", 1: "bounce_kernel", 2: "intersect_kernel", 3: "intersect_mfma_kernel", 4: "intersect_mfma_kernel"}[ctx.get_option("kernel_in_use")]
+        kname = {0: "pathtrace_mega_kernel", 1: "bounce_kernel", 2: "intersect_kernel", 3: "intersect_mfma_kernel", 4: "scan_solo_kernel"}[ctx.get_option("kernel_in_use")]
         if scan_launches == 0:
             kname = "whole frame (generate_rays + shade)"
         k = ctx.get_option("kernel_in_use")

@@ -236,21 +236,16 @@ struct MfVerifyLog { uint32_t n; uint32_t pad[3]; float ev[64][16]; };
 #ifndef MF_MIN_BLOCKS
 #define MF_MIN_BLOCKS 3      // waves per SIMD the register allocator must allow (four accumulator sets: 64 VGPRs)
 #endif
-// kSolo (kernel variant 4): ONE wave per SIMD.  The lost-survivor fault of this loop needs two waves on a SIMD:
-// with one block per CU the checksum of every examined minimum repeats exactly, in the shipped order AND with the examination
-// interleaved behind each product.  So the solo form interleaves (its own VALU work rides in the shadow of its own matrix
-// instructions), keeps the chunk's A tiles in LDS (loaded once per block, blocks are persistent over the ray blocks), and hands
-// survivors to a separate narrow-phase kernel through a global candidate buffer instead of stalling its only wave on the exact test.
-template <int S, bool kCount, bool kVerify = false, bool kSolo = false>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(kSolo ? 1 : MF_MIN_BLOCKS))) intersect_mfma_kernel(SceneView sc, WaveBuffers wb, MfView mf, uint32_t bounce,
+// (The one-wave-per-SIMD form of this scan, kernel variant 4, lives in rt_scan.hpp.)
+template <int S, bool kCount, bool kVerify = false>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MF_MIN_BLOCKS))) intersect_mfma_kernel(SceneView sc, WaveBuffers wb, MfView mf, uint32_t bounce,
                                                              uint32_t chunk_quads, Counters *__restrict__ counters, int debug_skip_exact)
 {
-    extern __shared__ uint4 lds_tiles[];                      // kSolo: the chunk's A tiles, [quad][tile][panel][row]
     // grid: x = blocks of 4 waves x S ray sets x 32 rays (grid-stride), y = chunks of `chunk_quads` quads (a chunk may start
     // in the middle of a group: the group's origin and bounds are set up at the first quad of every chunk as well)
     // per-wave survivor queue, entry = (ray in wave) << 16 | triangle offset in chunk.  Half a loop step (2 tiles x S ray sets
     // x 5 triangles x 64 lanes) can add at most kStepMax entries, and the queue is drained between half steps once it holds kDrain
-    constexpr uint32_t kStepMax = (kSolo ? 1 : kMfQuadTiles / 2) * S * 5 * 64, kDrain = 192, kQueue = kStepMax + kDrain;   // kSolo drains after every tile
+    constexpr uint32_t kStepMax = (kMfQuadTiles / 2) * S * 5 * 64, kDrain = 192, kQueue = kStepMax + kDrain;
     __shared__ uint32_t lds_queue[4 * kQueue];
     const uint32_t n_rays = wb.counts[bounce];
     const RayQueue qin = (bounce & 1u) ? wb.q[1] : wb.q[0];
@@ -273,12 +268,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(kSolo 
     // A tiles: every lane loads 16 bytes per tile (its row of its K panel) from base + a_off + 1024 t
     const char *A_bytes = reinterpret_cast<const char *>(mf.A);
     constexpr uint32_t kQuadBytes = kMfQuadTiles * 1024;
-    if (kSolo) {
-        const uint32_t n16 = (q_end - q_begin) * (kQuadBytes / 16u);
-        const uint4 *src = mf.A + (size_t)q_begin * (kQuadBytes / 16u);
-        for (uint32_t i = threadIdx.x; i < n16; i += 256u) lds_tiles[i] = src[i];
-        __syncthreads();
-    }
 
     for (uint32_t base = blockIdx.x * kRaysPerBlock; base < n_rays; base += gridDim.x * kRaysPerBlock) {
         MfRay ray[S];
@@ -301,20 +290,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(kSolo 
         const uint32_t wave_slot0 = base + (uint32_t)(wave * S) * 32u;
         auto flush = [&]() {
             fa.wave_slot0 = wave_slot0;
-            if (kSolo) {
-                // one atomicAdd per flush reserves room in the candidate buffer, the (queue slot, visit) pairs are written
-                // coalesced; what does not fit gets its exact test right here, so the result never depends on the buffer size
-                uint32_t at = 0;
-                if (lane == 0 && qn) at = atomicAdd(&wb.cand_counts[bounce], qn);
-                at = __shfl(at, 0);
-                for (uint32_t i = (uint32_t)lane; i < qn; i += 64u) {
-                    const uint32_t e = queue[i], pos = v_chunk_begin + (e & 0xffffu);
-                    const bool real = pos < v_chunk_end && (debug_skip_exact == 0 || debug_skip_exact >= 4);
-                    const uint32_t slot = wave_slot0 + (e >> 16), v = real ? mf.order[pos] : 0u;
-                    if (at + i < wb.cand_capacity) wb.cand[at + i] = make_uint2(real ? slot : 0xFFFFFFFFu, v);
-                    else if (real) exact_and_merge(sc, qin, best, slot, v);
-                }
-            } else mf_flush(fa, queue, qn);
+            mf_flush(fa, queue, qn);
             n_total += qn;
             qn = 0;
         };
@@ -322,16 +298,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(kSolo 
         // right in front of the MFMA that needs them: one exposed L2 round trip per tile).  Two register sets, the quad
         // loop is unrolled by two so that they swap roles without moves.
         uint32_t a_off = q_begin * kQuadBytes + (uint32_t)half * 512u + (uint32_t)col * 16u;
-        uint32_t l_off = (uint32_t)half * 32u + (uint32_t)col;          // kSolo: uint4 index into lds_tiles
-        const uint32_t l_last = (q_end - q_begin - 1u) * (kQuadBytes / 16u) + (uint32_t)half * 32u + (uint32_t)col;
         auto fetch_quad = [&](uint4 (&dst)[kMfQuadTiles]) {            // fetches the quad a_off points at, then advances
-            if (kSolo) {
-                const uint32_t o = min(l_off, l_last);                 // the prefetch behind the last quad of the chunk re-reads the last one
-#pragma unroll
-                for (int t = 0; t < kMfQuadTiles; ++t) dst[t] = lds_tiles[o + (uint32_t)(t * 64)];
-                l_off += kQuadBytes / 16u;
-                return;
-            }
 #pragma unroll
             for (int t = 0; t < kMfQuadTiles; ++t) dst[t] = *reinterpret_cast<const uint4 *>(A_bytes + a_off + (uint32_t)(t * 1024));
             a_off += kQuadBytes;                                       // the quad after the last one is the zero padding: in bounds
@@ -422,20 +389,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(kSolo 
         // its survivor set exactly (scripts/dbg_cand.py, scripts/dbg_soak.py, tests/test_gpu_fullsize.py).
         auto stage = [&](const uint4 &a, f32x16 (&nxt)[S], bool examine_pending, uint32_t pending_tile, f32x16 (&pend)[S]) {
             const bf16x8 Aop = __builtin_bit_cast(bf16x8, a);
-            if (kSolo) {
-                // one wave per SIMD: the S products, then the pending tile; no cross-wave effect to keep clear of, the compiler's own
-                // wait states for the register dependences are all that is needed (and its scheduler may mix the two).  VALU reads of
-                // MFMA-written registers are slow next to an in-flight MFMA of the same wave: ~115 cycles per product with S = 4,
-                // 127 with S = 2 and one ray set examined behind each product.
-#pragma unroll
-                for (int s = 0; s < S; ++s) nxt[s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Aop, B[s], zero, 0, 0, 0);
-                // (pinning all accumulators so that the products stay back to back was measured: 240 instead of 254 Mpaths/s; the
-                // scheduler's own interleaving is kept)
-                asm volatile("" : "+v"(accX[0]), "+v"(accX[S - 1]), "+v"(accY[0]), "+v"(accY[S - 1]));
-                if (examine_pending) examine(pending_tile, pend);
-                if (qn >= kDrain) flush();
-                return;
-            }
 #if MF_ISSUE_GAP >= 0
             asm volatile("s_nop %0" :: "n"(MF_ISSUE_GAP) : "memory");          // no register operands: pinning the accumulators here cost 5%
 #endif
@@ -500,18 +453,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(kSolo 
     if (kCount) {
         atomicAdd(&counters->candidates, c_cand_total);
         if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&counters->tri_tests, (unsigned long long)n_rays * (v_chunk_end - v_chunk_begin));
-    }
-}
-
-// ---- narrow phase of the solo variant: one lane per surviving (ray, triangle) pair, exact reference-order test, atomicMin merge
-__global__ void __launch_bounds__(256) narrow_phase_kernel(SceneView sc, WaveBuffers wb, uint32_t bounce)
-{
-    const uint32_t n = min(wb.cand_counts[bounce], wb.cand_capacity);
-    const RayQueue qin = (bounce & 1u) ? wb.q[1] : wb.q[0];
-    unsigned long long *best = (bounce & 1u) ? wb.best[1] : wb.best[0];
-    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
-        const uint2 c = wb.cand[i];
-        if (c.x != 0xFFFFFFFFu) exact_and_merge(sc, qin, best, c.x, c.y);
     }
 }
 

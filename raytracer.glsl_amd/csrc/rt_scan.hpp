@@ -1,0 +1,363 @@
+// rt_scan.hpp -- kernel variant 4 (default): the bf16 matrix-core broad phase of rt_mfma.hpp with ONE wave per SIMD and a
+// hand-ordered instruction stream.
+//
+// The broad phase of find_closest_mesh (:331-361) is the same contraction as in rt_mfma.hpp (same A tiles, same B operand,
+// same threshold, same margin proof): F~[edge row][ray] per (tile of 10 triangles, set of 32 rays) from ONE
+// v_mfma_f32_32x32x16_bf16, then "does any triangle of this lane survive" = 5 v_min3 + 2 v_max3 + 1 v_cmp on the 16 results.
+// What this file changes is the schedule.  With one wave on a SIMD nothing else fills a stall, so the order of the wave's
+// own instructions decides the speed (MI355X_MICROARCH.md: an MFMA occupies the matrix pipe for 32 cycles but holds the
+// vector issue port for 8 only; a VALU instruction costs 4):
+//
+//     tile t:   mfma  X0 <- A_t B_0     8 VALU examining Y0 (tile t-1, set 0)
+//               mfma  X1 <- A_t B_1     8 VALU examining Y1
+//               ...                      (S sets; then ONE scalar branch on "any survivor in tile t-1")
+//     tile t+1: the same with X and Y swapped
+//
+// i.e. every examination reads an accumulator whose matrix instruction was issued S products (>= 160 cycles) earlier, and
+// every matrix instruction is followed by exactly the 8 vector instructions that fit beside it.  The compiler's own order
+// for the same source was "S products back to back, then 8 S VALU" (nothing overlaps: 125 cycles per product measured in
+// round 1); the order above is imposed with __builtin_amdgcn_sched_group_barrier and verified in the ISA (make asm).
+//
+// Also per block: the chunk's A tiles live in LDS (loaded once, blocks are persistent over ray blocks); the rays of the NEXT
+// ray block are fetched while the current one is scanned; survivors go to a per-wave LDS queue and from there to the global
+// candidate buffer of the narrow-phase kernel (64-bit counter; what does not fit is tested in place).
+#pragma once
+#include "rt_mfma.hpp"
+
+#pragma clang fp contract(off)
+
+namespace rt {
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+
+constexpr int kSoloSets = 4;                                      // 32-ray sets per wave: 512 rays per block of four waves
+struct SoloCfg {
+    static constexpr uint32_t kStepMax = (uint32_t)kSoloSets * 5u * 64u;     // one examined tile adds at most S x 5 triangles x 64 lanes entries
+    static constexpr uint32_t kDrain = 192u;                          // the queue is handed over once it holds this many
+    static constexpr uint32_t kQueue = kStepMax + kDrain;             // entries per wave
+    static constexpr uint32_t kRaysPerBlock = 4u * (uint32_t)kSoloSets * 32u;
+};
+
+// ---- the hand-ordered instruction stream ---------------------------------------------------------------------------------------
+// Register map of the hot loop (one wave per SIMD owns the whole file; VALU instructions address v0..v255 only, so everything
+// the examination reads has to sit there):
+//     X0..X3 = v[128:143] v[144:159] v[160:175] v[176:191]      accumulators of the tile in flight / pending, by ray set
+//     Y0..Y3 = v[192:207] v[208:223] v[224:239] v[240:255]
+//     MA0..3 = v[96:103] v[104:111] v[112:119] v[120:127]       minima (5 per set, slot 5 = their maximum) written by a Y stage
+//     MB0..3 = v[64:71]  v[72:79]   v[80:87]   v[88:95]         ... by an X stage
+//     KA = s[20:27], KB = s[28:35]                              "lanes with a survivor" per ray set of the last Y / X stage
+// The blocks are bound with physical-register constraints, so the compiler sees ordinary dataflow (it keeps its own values out of
+// the way and orders loads and waits), while the ORDER inside a statement is exactly what is written.
+//
+// One statement = one trip of the steady loop = two pipeline stages of 4 x (one matrix instruction, the 8 vector instructions
+// examining the block the previous stage produced for the same ray set), then ONE group of scalar instructions that folds the
+// eight "lanes with a survivor" masks into two scalars.  Measured with tools/scan_stage_rate.hip on MI355X (one wave per SIMD):
+// the pure vector stream runs at 44-46 cycles per product; every place where scalar instructions interrupt it costs ~40 cycles,
+// however few they are, and a scalar instruction that reads a mask a v_cmp has just written stalls for another ~30.  Hence one
+// scalar spot per TWO stages (the fold, directly followed by the compiler's compare-and-branch, loop control and the LDS reads of
+// the next two tiles), with the freshest mask folded last; the rare "park the survivors" path runs behind the statement, off the
+// minima the statement leaves in MA (first stage) and MB (second stage).
+// Hazards the compiler cannot see (it does not look into inline asm):
+//   * MFMA result -> VALU read of the same block: a block is read one stage after it was written, i.e. at least 3 MFMAs and 27
+//     VALU instructions later (>= 12 wait states needed for this 8-pass MFMA, tools/mfma_hazard_probe.hip); prologue and epilogue
+//     of a segment put a full s_nop 15 in between;
+//   * VALU write -> MFMA overwrite of a block (the M registers are outside the blocks) and MFMA source operands written by VALU:
+//     no wait states required on gfx950.
+#define RT_EXAM(PL, ML, KL, TH) \
+    "v_min3_f32 v[" #ML "+0], v[" #PL "+0], v[" #PL "+1], v[" #PL "+2]\n\t" \
+    "v_min3_f32 v[" #ML "+1], v[" #PL "+3], v[" #PL "+4], v[" #PL "+5]\n\t" \
+    "v_min3_f32 v[" #ML "+2], v[" #PL "+6], v[" #PL "+7], v[" #PL "+8]\n\t" \
+    "v_min3_f32 v[" #ML "+3], v[" #PL "+9], v[" #PL "+10], v[" #PL "+11]\n\t" \
+    "v_min3_f32 v[" #ML "+4], v[" #PL "+12], v[" #PL "+13], v[" #PL "+14]\n\t" \
+    "v_max3_f32 v[" #ML "+5], v[" #ML "+0], v[" #ML "+1], v[" #ML "+2]\n\t" \
+    "v_max3_f32 v[" #ML "+5], v[" #ML "+5], v[" #ML "+3], v[" #ML "+4]\n\t" \
+    "v_cmp_nle_f32_e64 s[" #KL ":" #KL "+1], v[" #ML "+5], " TH "\n\t"
+#define RT_MFMA(NL, AOP, B) "v_mfma_f32_32x32x16_bf16 v[" #NL ":" #NL "+15], " AOP ", " B ", 0\n\t"
+#define RT_FOLD(ANY, KL) "s_or_b64 " ANY ", s[" #KL ":" #KL "+1], s[" #KL "+2:" #KL "+3]\n\ts_or_b64 " ANY ", " ANY ", s[" #KL "+4:" #KL "+5]\n\ts_or_b64 " ANY ", " ANY ", s[" #KL "+6:" #KL "+7]\n\t"
+#define RT_STAGE_Y_TEXT(AOP) RT_MFMA(192, AOP, "%[b0]") RT_EXAM(128, 96, 20, "%[t0]") RT_MFMA(208, AOP, "%[b1]") RT_EXAM(144, 104, 22, "%[t1]") \
+                             RT_MFMA(224, AOP, "%[b2]") RT_EXAM(160, 112, 24, "%[t2]") RT_MFMA(240, AOP, "%[b3]") RT_EXAM(176, 120, 26, "%[t3]")
+#define RT_STAGE_X_TEXT(AOP) RT_MFMA(128, AOP, "%[b0]") RT_EXAM(192, 64, 28, "%[t0]") RT_MFMA(144, AOP, "%[b1]") RT_EXAM(208, 72, 30, "%[t1]") \
+                             RT_MFMA(160, AOP, "%[b2]") RT_EXAM(224, 80, 32, "%[t2]") RT_MFMA(176, AOP, "%[b3]") RT_EXAM(240, 88, 34, "%[t3]")
+#define RT_K_CLOBBERS "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27", "s28", "s29", "s30", "s31", "s32", "s33", "s34", "s35"
+// two stages: tile t (operand AY) -> Y while X (tile t-1) is examined into MA; tile t+1 (operand AX) -> X while Y is examined into MB
+#define RT_TRIP(AY, AX) \
+    asm volatile(RT_STAGE_Y_TEXT("%[ay]") RT_STAGE_X_TEXT("%[ax]") RT_FOLD("%[anya]", 20) RT_FOLD("%[anyb]", 28) \
+                 : "+{v[128:143]}"(X0), "+{v[144:159]}"(X1), "+{v[160:175]}"(X2), "+{v[176:191]}"(X3), \
+                   "=&{v[192:207]}"(Y0), "=&{v[208:223]}"(Y1), "=&{v[224:239]}"(Y2), "=&{v[240:255]}"(Y3), \
+                   "=&{v[96:103]}"(MA0), "=&{v[104:111]}"(MA1), "=&{v[112:119]}"(MA2), "=&{v[120:127]}"(MA3), \
+                   "=&{v[64:71]}"(MB0), "=&{v[72:79]}"(MB1), "=&{v[80:87]}"(MB2), "=&{v[88:95]}"(MB3), [anya] "=&s"(any_a), [anyb] "=&s"(any_b) \
+                 : [ay] "v"(AY), [ax] "v"(AX), [b0] "v"(B0), [b1] "v"(B1), [b2] "v"(B2), [b3] "v"(B3), [t0] "v"(th0), [t1] "v"(th1), [t2] "v"(th2), [t3] "v"(th3) \
+                 : RT_K_CLOBBERS)
+// a single stage (a segment with an even number of tiles ends with one), the products of a segment's first tile, and the
+// examination of its last one (nothing to overlap with)
+#define RT_STAGE_Y(AY) \
+    asm volatile(RT_STAGE_Y_TEXT("%[ay]") RT_FOLD("%[anya]", 20) \
+                 : "=&{v[192:207]}"(Y0), "=&{v[208:223]}"(Y1), "=&{v[224:239]}"(Y2), "=&{v[240:255]}"(Y3), \
+                   "=&{v[96:103]}"(MA0), "=&{v[104:111]}"(MA1), "=&{v[112:119]}"(MA2), "=&{v[120:127]}"(MA3), [anya] "=&s"(any_a) \
+                 : "{v[128:143]}"(X0), "{v[144:159]}"(X1), "{v[160:175]}"(X2), "{v[176:191]}"(X3), \
+                   [ay] "v"(AY), [b0] "v"(B0), [b1] "v"(B1), [b2] "v"(B2), [b3] "v"(B3), [t0] "v"(th0), [t1] "v"(th1), [t2] "v"(th2), [t3] "v"(th3) \
+                 : RT_K_CLOBBERS)
+#define RT_PRODUCTS_X(AOP) \
+    asm volatile(RT_MFMA(128, "%[a]", "%[b0]") RT_MFMA(144, "%[a]", "%[b1]") RT_MFMA(160, "%[a]", "%[b2]") RT_MFMA(176, "%[a]", "%[b3]") "s_nop 15" \
+                 : "=&{v[128:143]}"(X0), "=&{v[144:159]}"(X1), "=&{v[160:175]}"(X2), "=&{v[176:191]}"(X3) \
+                 : [a] "v"(AOP), [b0] "v"(B0), [b1] "v"(B1), [b2] "v"(B2), [b3] "v"(B3))
+#define RT_EXAMINE_X() \
+    asm volatile("s_nop 15\n\t" RT_EXAM(128, 96, 20, "%[t0]") RT_EXAM(144, 104, 22, "%[t1]") RT_EXAM(160, 112, 24, "%[t2]") RT_EXAM(176, 120, 26, "%[t3]") "s_nop 7" \
+                 : "=&{v[96:103]}"(MA0), "=&{v[104:111]}"(MA1), "=&{v[112:119]}"(MA2), "=&{v[120:127]}"(MA3) \
+                 : "{v[128:143]}"(X0), "{v[144:159]}"(X1), "{v[160:175]}"(X2), "{v[176:191]}"(X3), [t0] "v"(th0), [t1] "v"(th1), [t2] "v"(th2), [t3] "v"(th3) \
+                 : RT_K_CLOBBERS)
+#define RT_EXAMINE_Y() \
+    asm volatile("s_nop 15\n\t" RT_EXAM(192, 64, 28, "%[t0]") RT_EXAM(208, 72, 30, "%[t1]") RT_EXAM(224, 80, 32, "%[t2]") RT_EXAM(240, 88, 34, "%[t3]") "s_nop 7" \
+                 : "=&{v[64:71]}"(MB0), "=&{v[72:79]}"(MB1), "=&{v[80:87]}"(MB2), "=&{v[88:95]}"(MB3) \
+                 : "{v[192:207]}"(Y0), "{v[208:223]}"(Y1), "{v[224:239]}"(Y2), "{v[240:255]}"(Y3), [t0] "v"(th0), [t1] "v"(th1), [t2] "v"(th2), [t3] "v"(th3) \
+                 : RT_K_CLOBBERS)
+
+// diagnostics build (-DRT_SOLO_STAMPS): s_memtime stamps around the phases of a wave's life, summed into mf.dbg_log
+#ifdef RT_SOLO_STAMPS
+#define RT_STAMP(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+#define RT_STAMP_ADD(acc, from, to) acc += (to) - (from)
+#else
+#define RT_STAMP(var)
+#define RT_STAMP_ADD(acc, from, to)
+#endif
+
+template <bool kCount>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+scan_solo_kernel(SceneView sc, WaveBuffers wb, MfView mf, uint32_t bounce, uint32_t chunk_quads, Counters *__restrict__ counters, int debug_skip_exact)
+{
+    using Cfg = SoloCfg;
+    constexpr int S = kSoloSets;
+    extern __shared__ uint4 lds_tiles[];                      // the chunk's A tiles, [quad][tile][panel][row]
+    __shared__ uint32_t lds_queue[4 * Cfg::kQueue];          // per-wave survivor queue, entry = (ray in wave) << 16 | triangle offset in chunk
+    RT_STAMP(ts_begin);
+#ifdef RT_SOLO_STAMPS
+    unsigned long long tt_stage = 0, tt_rays = 0, tt_group = 0, tt_steady = 0, tt_park = 0, tt_flush = 0, tt_iters = 0;
+#endif
+    const uint32_t n_rays = wb.counts[bounce];
+    const RayQueue qin = (bounce & 1u) ? wb.q[1] : wb.q[0];
+    unsigned long long *best = (bounce & 1u) ? wb.best[1] : wb.best[0];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, col = lane & 31, half = lane >> 5;
+    // only quads that hold triangles; the padding rows inside the last one carry a -3e38 bias and never survive
+    const uint32_t q_begin = blockIdx.y * chunk_quads, q_end = min(q_begin + chunk_quads, min(mf.n_quads, (sc.n_tri_visits + kMfQuadTris - 1u) / kMfQuadTris));
+    // survivors of this wave go to ITS region of the candidate buffer: no atomic, no round trip the single wave of a SIMD would wait for
+    const uint32_t region = (blockIdx.y * gridDim.x + blockIdx.x) * 4u + (uint32_t)wave;
+    uint2 *const cand = wb.cand + (size_t)region * wb.cand_region;
+    unsigned long long appended = 0;                           // wave-uniform; pairs beyond the region's capacity are tested in place
+    if (q_begin >= q_end) { if (lane == 0) wb.cand_counts[region] = 0u; return; }
+    const uint32_t v_chunk_begin = q_begin * kMfQuadTris, v_chunk_end = min(q_end * (uint32_t)kMfQuadTris, sc.n_tri_visits);
+    const uint32_t group_shift = (uint32_t)__builtin_ctz(mf.group_quads);
+    const uint32_t n_tiles = (q_end - q_begin) * kMfQuadTiles;
+    constexpr uint32_t kQuadBytes = kMfQuadTiles * 1024;
+    {
+        const uint32_t n16 = (q_end - q_begin) * (kQuadBytes / 16u);
+        const uint4 *src = mf.A + (size_t)q_begin * (kQuadBytes / 16u);
+        // eight loads in flight per thread (a plain copy loop waits for every load: 32 exposed L2 round trips per launch)
+        for (uint32_t i0 = threadIdx.x; i0 < n16; i0 += 8u * 256u) {
+            uint4 v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { const uint32_t i = i0 + (uint32_t)k * 256u; v[k] = src[min(i, n16 - 1u)]; }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { const uint32_t i = i0 + (uint32_t)k * 256u; if (i < n16) lds_tiles[i] = v[k]; }
+        }
+        __syncthreads();
+    }
+    RT_STAMP(ts_staged);
+    RT_STAMP_ADD(tt_stage, ts_begin, ts_staged);
+    uint32_t *queue = lds_queue + wave * Cfg::kQueue;
+    typedef const float __attribute__((address_space(4))) *ConstFloats;       // group records: uniform index => s_load
+    const ConstFloats groups_k = (ConstFloats)(uintptr_t)mf.groups;
+    const uint32_t l_lane = (uint32_t)half * 32u + (uint32_t)col;              // this lane's row inside a tile (uint4 index)
+    unsigned long long c_cand_total = 0;
+
+    // rays of one block as they sit in the queue: both lane halves hold the same ray
+    float4 nxt_a[S], nxt_b[S];
+    auto fetch_rays = [&](uint32_t base) {
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            const uint32_t slot = base + (uint32_t)(wave * S + s) * 32u + (uint32_t)col;
+            nxt_a[s] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); nxt_b[s] = nxt_a[s];
+            if (slot < n_rays) { nxt_a[s] = qin.a[slot]; nxt_b[s] = qin.b[slot]; }
+        }
+    };
+    fetch_rays(blockIdx.x * Cfg::kRaysPerBlock);
+
+    for (uint32_t base = blockIdx.x * Cfg::kRaysPerBlock; base < n_rays; base += gridDim.x * Cfg::kRaysPerBlock) {
+        RT_STAMP(ts_iter);
+        MfRay ray[S];
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            const uint32_t slot = base + (uint32_t)(wave * S + s) * 32u + (uint32_t)col;
+            MfRay &r = ray[s];
+            r.valid = slot < n_rays;
+            r.o = mk(nxt_a[s].x, nxt_a[s].y, nxt_a[s].z); r.d = mk(nxt_a[s].w, nxt_b[s].x, nxt_b[s].y);
+            r.wd = __builtin_sqrtf(dot3(r.d, r.d)) * 1.001f;
+            r.wod = (__builtin_sqrtf(dot3(r.o, r.o)) * 1.001f) * r.wd;
+            const uint32_t dxy = pack_bf16(r.d.x, r.d.y);
+            r.dyz = pack_bf16(r.d.y, r.d.z);
+            r.dx_hi = dxy << 16;
+            const f3 dl = mk(r.d.x - __uint_as_float(dxy << 16), r.d.y - __uint_as_float(dxy & 0xffff0000u), r.d.z - __uint_as_float(r.dyz & 0xffff0000u));
+            r.tail = half ? pack_bf16(dl.y, dl.z) : pack_bf16(1.0f, dl.x);
+        }
+        // the next block's rays travel while this one is scanned (one wave per SIMD: nothing else would hide the round trip)
+        if (base + gridDim.x * Cfg::kRaysPerBlock < n_rays) fetch_rays(base + gridDim.x * Cfg::kRaysPerBlock);
+
+        uint32_t qn = 0, n_total = 0;                            // wave-uniform
+        const uint32_t wave_slot0 = base + (uint32_t)(wave * S) * 32u;
+        auto flush = [&]() {
+            // the (queue slot, storage position) pairs are appended to the wave's region, coalesced, fire and forget (the narrow
+            // phase maps storage position -> visit index); what does not fit gets its exact test right here, so the result never
+            // depends on the buffer size.  `appended` is 64 bits wide: a degenerate scene (NaN bounds: every pair survives) can
+            // exceed 2^32 pairs per wave.
+            for (uint32_t i = (uint32_t)lane; i < qn; i += 64u) {
+                const uint32_t e = queue[i], pos = v_chunk_begin + (e & 0xffffu);
+                const bool real = pos < v_chunk_end && (debug_skip_exact == 0 || debug_skip_exact >= 4);
+                const uint32_t slot = wave_slot0 + (e >> 16);
+                if (appended + i < (unsigned long long)wb.cand_region) cand[appended + i] = make_uint2(real ? slot : 0xFFFFFFFFu, pos);
+                else if (real) exact_and_merge(sc, qin, best, slot, mf.order[pos]);
+            }
+            appended += qn;
+            n_total += qn;
+            qn = 0;
+        };
+
+        u32x4 B0, B1, B2, B3;                                   // B operands (K layout: see MfView) and thresholds of the four ray sets
+        float th0, th1, th2, th3;
+        f32x16 X0, X1, X2, X3, Y0, Y1, Y2, Y3;
+        f32x8 MA0, MA1, MA2, MA3, MB0, MB1, MB2, MB3;            // [0..4]: minima of the five triangles of the lane's half
+        unsigned long long any_a, any_b;                        // lanes with a survivor in the tile examined into MA / MB
+        // rare path: some lane has a survivor in `tile` (index inside the chunk) -> per (ray set, triangle) ballots, survivors
+        // into the wave's LDS queue.  A finite threshold means finite operands and edge values below 2^7 * 1e30 in magnitude,
+        // hence finite minima: max-of-minima > threshold is then exactly "some triangle of this lane survives"; a NaN threshold
+        // passes all.
+        auto park_set = [&](uint32_t tile, int s, const f32x8 &mq, float th) {
+#pragma unroll
+            for (int u = 0; u < 5; ++u) {
+                const unsigned long long m = __builtin_amdgcn_ballot_w64(!(mq[u] <= th));
+                if (m) {                                                        // wave-uniform
+                    if ((m >> lane) & 1ull) {
+                        const uint32_t v_off = tile * kMfTileTris + 5u * (uint32_t)half + (uint32_t)u;
+                        queue[qn + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = ((uint32_t)(s * 32 + col) << 16) | v_off;
+                    }
+                    qn += (uint32_t)__popcll(m);
+                }
+            }
+        };
+        // (slot 5 of a minima block is the maximum of the five: the per-set "anything here?" is re-derived from it instead of from the
+        // stage's scalar masks, which then never leave their registers)
+        auto park = [&](uint32_t tile, const f32x8 &M0, const f32x8 &M1, const f32x8 &M2, const f32x8 &M3) {
+            RT_STAMP(ts_p0);
+            if (__builtin_amdgcn_ballot_w64(!(M0[5] <= th0))) park_set(tile, 0, M0, th0);
+            if (__builtin_amdgcn_ballot_w64(!(M1[5] <= th1))) park_set(tile, 1, M1, th1);
+            if (__builtin_amdgcn_ballot_w64(!(M2[5] <= th2))) park_set(tile, 2, M2, th2);
+            if (__builtin_amdgcn_ballot_w64(!(M3[5] <= th3))) park_set(tile, 3, M3, th3);
+            if (qn >= Cfg::kDrain) flush();
+            RT_STAMP(ts_p1);
+            RT_STAMP_ADD(tt_park, ts_p0, ts_p1);
+        };
+        RT_STAMP(ts_rays);
+        RT_STAMP_ADD(tt_rays, ts_iter, ts_rays);
+
+        // segments = runs of tiles that share one group (local origin + bounds); a chunk may start or end inside a group
+        for (uint32_t t0 = 0; t0 < n_tiles;) {
+            RT_STAMP(ts_g0);
+            const uint32_t q = q_begin + t0 / kMfQuadTiles;
+            const uint32_t g = q >> group_shift;
+            const uint32_t t1 = min(n_tiles, (((g + 1u) << group_shift) - q_begin) * kMfQuadTiles);
+            const ConstFloats gp = groups_k + (size_t)g * (sizeof(MfGroup) / 4);
+            MfGroup G;
+            G.cx = gp[0]; G.cy = gp[1]; G.cz = gp[2]; G.E = gp[3]; G.Ml = gp[4]; G.Pw = gp[5]; G.P = gp[6]; G.pad1 = 0.0f;
+            u32x4 Bs[S]; float ths[S];
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                const MfRay &r = ray[s];
+                const f3 ol = r.o - mk(G.cx, G.cy, G.cz);
+                const f3 cvl = cross3(r.d, ol);
+                // v_sqrt_f32 (1 ulp) instead of the correctly rounded sequence: these are bounds, inflated by 1.001
+                const float ncv = __builtin_amdgcn_sqrtf(dot3(cvl, cvl)) * 1.001f, no = __builtin_amdgcn_sqrtf(dot3(ol, ol)) * 1.001f;
+                const float margin = mf_margin(G, ncv, no, r);
+                // empty slot: nothing survives.  Margin not finite or so large that the bf16 products could overflow (bounds NaN for
+                // non-finite vertices, huge coordinates): NaN threshold, everything survives.
+                ths[s] = (!r.valid || debug_skip_exact == 2) ? __builtin_inff() : (margin < 1.0e30f ? -margin : __builtin_nanf(""));
+                Bs[s].x = pack_bf16(cvl.x, cvl.y);
+                Bs[s].y = (pack_bf16(cvl.z, 0.0f) & 0xffffu) | r.dx_hi;
+                Bs[s].z = r.dyz; Bs[s].w = r.tail;
+            }
+            B0 = Bs[0]; B1 = Bs[1]; B2 = Bs[2]; B3 = Bs[3];
+            th0 = ths[0]; th1 = ths[1]; th2 = ths[2]; th3 = ths[3];
+            // prologue: the products of the segment's first tile.  The tile rows of a trip are read during the trip before; the two rows
+            // behind the chunk's last tile are allocated (and never used).
+            const uint4 *row = lds_tiles + (size_t)t0 * 64u + l_lane;
+            auto tile_row = [&]() { const uint4 r = *row; row += 64; return u32x4{r.x, r.y, r.z, r.w}; };
+            u32x4 ap = tile_row(), ay = tile_row(), ax = tile_row();
+            RT_PRODUCTS_X(ap);
+            RT_STAMP(ts_g1);
+            RT_STAMP_ADD(tt_group, ts_g0, ts_g1);
+            // steady state: two stages per trip (tile t -> Y beside the examination of tile t-1, tile t+1 -> X beside the examination
+            // of tile t), so that X and Y swap roles without moves
+            uint32_t t = t0 + 1u;
+            for (; t + 1u < t1; t += 2u) {
+                RT_TRIP(ay, ax);
+                ay = tile_row(); ax = tile_row();
+                if (__builtin_expect((any_a | any_b) != 0ull, 0)) {
+                    if (any_a) park(t - 1u, MA0, MA1, MA2, MA3);
+                    if (any_b) park(t, MB0, MB1, MB2, MB3);
+                }
+            }
+            // epilogue: a last single stage if the segment's tile count is even, then the examination of the last tile (park() finds
+            // nothing when there is nothing)
+            if (t < t1) {
+                RT_STAGE_Y(ay);
+                if (any_a) park(t - 1u, MA0, MA1, MA2, MA3);
+                RT_EXAMINE_Y();
+                park(t, MB0, MB1, MB2, MB3);
+            } else {
+                RT_EXAMINE_X();
+                park(t - 1u, MA0, MA1, MA2, MA3);
+            }
+            t0 = t1;
+            RT_STAMP(ts_g2);
+            RT_STAMP_ADD(tt_steady, ts_g1, ts_g2);
+        }
+        RT_STAMP(ts_f0);
+        flush();
+        RT_STAMP(ts_f1);
+        RT_STAMP_ADD(tt_flush, ts_f0, ts_f1);
+#ifdef RT_SOLO_STAMPS
+        tt_iters++;
+#endif
+        c_cand_total += (lane == 0) ? n_total : 0u;
+    }
+#ifdef RT_SOLO_STAMPS
+    if (lane == 0 && mf.dbg_log) {
+        unsigned long long *d = reinterpret_cast<unsigned long long *>(mf.dbg_log) + 16ull * bounce;
+        const unsigned long long ts_end = __builtin_amdgcn_s_memtime();
+        atomicAdd(d + 0, ts_end - ts_begin); atomicAdd(d + 1, tt_stage); atomicAdd(d + 2, tt_rays); atomicAdd(d + 3, tt_group);
+        atomicAdd(d + 4, tt_steady); atomicAdd(d + 5, tt_park); atomicAdd(d + 6, tt_flush); atomicAdd(d + 7, tt_iters); atomicAdd(d + 8, 1ull);
+        atomicAdd(d + 9, (unsigned long long)n_tiles * tt_iters);
+    }
+#endif
+    if (lane == 0) wb.cand_counts[region] = (uint32_t)(appended < (unsigned long long)wb.cand_region ? appended : (unsigned long long)wb.cand_region);
+    if (kCount) {
+        atomicAdd(&counters->candidates, c_cand_total);
+        if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&counters->tri_tests, (unsigned long long)n_rays * (v_chunk_end - v_chunk_begin));
+    }
+}
+
+// ---- narrow phase: one lane per surviving (ray, triangle) pair, exact reference-order test (:243-249), atomicMin merge.
+// One block per wave region of the scan launch that preceded it (grid-stride over regions).
+__global__ void __launch_bounds__(256) narrow_phase_kernel(SceneView sc, WaveBuffers wb, MfView mf, uint32_t bounce, uint32_t n_regions)
+{
+    const RayQueue qin = (bounce & 1u) ? wb.q[1] : wb.q[0];
+    unsigned long long *best = (bounce & 1u) ? wb.best[1] : wb.best[0];
+    for (uint32_t r = blockIdx.x; r < n_regions; r += gridDim.x) {
+        const uint32_t n = min(wb.cand_counts[r], wb.cand_region);
+        const uint2 *cand = wb.cand + (size_t)r * wb.cand_region;
+        for (uint32_t i = threadIdx.x; i < n; i += 256u) {
+            const uint2 c = cand[i];
+            if (c.x != 0xFFFFFFFFu) exact_and_merge(sc, qin, best, c.x, mf.order[c.y]);
+        }
+    }
+}
+
+}  // namespace rt

@@ -44,9 +44,10 @@ struct WaveBuffers {
     uint4 *pix_rng;       // per local pixel RNG state between samples (only u_samples > 1)
     const float2 *group_bounds;   // per kBoundGroup triangles: (max bound_e, max bound_m)
     unsigned long long *best[2];  // split pipeline: per queue slot, packed (t bits << 32 | visit index) of the nearest mesh hit
-    uint2 *cand;                  // kernel 4: (queue slot, visit index) pairs that survived the broad phase of the current bounce
-    uint32_t *cand_counts;        // kernel 4: cand_counts[b] = pairs appended during bounce b (may exceed cand_capacity)
-    uint32_t cand_capacity;
+    uint2 *cand;                  // kernel 4: (queue slot, storage position) pairs that survived the broad phase of the current bounce,
+                                  // one region of `cand_region` pairs per wave of the scan launch
+    uint32_t *cand_counts;        // kernel 4: pairs stored in each region by the scan launch of the current bounce
+    uint32_t cand_region;         // capacity of one region (pairs); what does not fit is tested in place by the scan
 };
 
 struct PathState { f3 o, d, thr, rad; Rng rng; uint32_t pixel; };

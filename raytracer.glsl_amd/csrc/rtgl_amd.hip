@@ -12,6 +12,7 @@
 #include "rt_device.hpp"
 #include "rt_wavefront.hpp"
 #include "rt_mfma.hpp"
+#include "rt_scan.hpp"
 
 #pragma clang fp contract(off)
 
@@ -184,7 +185,8 @@ struct rtgl_context {
     hipEvent_t counts_ev = nullptr; bool counts_pending = false, counts_valid = false;
     bool timing_this_frame = false; uint32_t timing_frame_counter = 0;
     int kernel_in_use = -1;                  // variant the last frame actually ran
-    bool wave_has_cand = false; int n_cus = 256;
+    bool wave_has_cand = false; int n_cus = 256; uint32_t cand_regions = 0;
+    bool solo_attr_set = false;              // hipFuncAttributeMaxDynamicSharedMemorySize is per device: raised once per context (= per device binding)
     bool kernel_explicit = false;            // "kernel" was set through rtgl_set_option or RTGL_AMD_KERNEL
     uint32_t counts_n0 = 0, counts_len = 0;
     std::vector<uint32_t> est_counts;        // grid-size estimates for the next frame
@@ -269,8 +271,21 @@ extern "C" void rtgl_destroy(rtgl_context *ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+#ifdef RT_SOLO_STAMPS
+    if (ctx->d_dbg_log) {      // diagnostics build: where the waves of the solo scan spent their cycles, per bounce, summed over all frames
+        unsigned long long h[16 * 64];
+        if (hipMemcpy(h, ctx->d_dbg_log, sizeof h, hipMemcpyDeviceToHost) == hipSuccess)
+            for (int b = 0; b < 64 && h[16 * b + 8]; ++b) {
+                const unsigned long long *d = h + 16 * b; const double tot = (double)d[0];
+                fprintf(stderr, "rtgl stamps bounce %2d: waves %llu iters %llu  cycles/wave %.0f  staging %.1f%% rays %.1f%% group+prologue %.1f%% steady %.1f%% (park %.1f%%) flush %.1f%%  cycles per tile-stage in steady %.1f\n",
+                        b, d[8], d[7], tot / d[8], 100.0 * d[1] / tot, 100.0 * d[2] / tot, 100.0 * d[3] / tot, 100.0 * d[4] / tot, 100.0 * d[5] / tot, 100.0 * d[6] / tot,
+                        d[9] ? (double)d[4] / (double)d[9] : 0.0);
+            }
+    }
+#endif
     void *ptrs[] = { ctx->d_spheres, ctx->d_materials, ctx->d_vertices, ctx->d_sphere_visits, ctx->d_edges, ctx->d_planes,
-                     ctx->d_env, ctx->d_image_own, ctx->d_rng, ctx->d_counters, ctx->d_u8, ctx->d_group_bounds, ctx->d_wave, ctx->d_counts, ctx->d_mf_groups, ctx->d_mf_A, ctx->d_mf_order };
+                     ctx->d_env, ctx->d_image_own, ctx->d_rng, ctx->d_counters, ctx->d_u8, ctx->d_group_bounds, ctx->d_wave, ctx->d_counts, ctx->d_mf_groups, ctx->d_mf_A, ctx->d_mf_order,
+                     ctx->d_dbg_log };
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (hipEvent_t e : ctx->kev) (void)hipEventDestroy(e);
     if (ctx->h_counts) (void)hipHostFree(ctx->h_counts);
@@ -483,11 +498,17 @@ static void kev_mark(rtgl_context *ctx)
 }
 
 // ---- bounce-wavefront pipeline: buffers + launches ------------------------------------------------
+// kernel 4 launches at most max(CUs, chunks) blocks of four waves; each wave owns one region of the candidate buffer
+static uint32_t solo_chunks(const rtgl_context *ctx);
+static uint32_t solo_regions(const rtgl_context *ctx) { return std::max<uint32_t>((uint32_t)ctx->n_cus, solo_chunks(ctx)) * 4u; }
+
+static size_t counts_bytes(uint32_t capacity) { return (size_t)capacity * sizeof(uint32_t); }
+
 static int ensure_wave_buffers(rtgl_context *ctx, uint32_t n0, uint32_t max_bounce, bool multi_sample)
 {
     if (ctx->counts_capacity < max_bounce + 2) {
         if (ctx->d_counts) { HIPCHK(ctx, hipFree(ctx->d_counts)); ctx->d_counts = nullptr; }
-        HIPCHK(ctx, hipMalloc((void **)&ctx->d_counts, (size_t)(max_bounce + 2) * 2 * sizeof(uint32_t)));       // ray counts, then candidate counts (kernel 4)
+        HIPCHK(ctx, hipMalloc((void **)&ctx->d_counts, counts_bytes(max_bounce + 2)));                          // u32 ray counts per bounce
         if (ctx->h_counts) { HIPCHK(ctx, hipHostFree(ctx->h_counts)); ctx->h_counts = nullptr; }
         HIPCHK(ctx, hipHostMalloc((void **)&ctx->h_counts, (size_t)(max_bounce + 2) * sizeof(uint32_t), hipHostMallocDefault));
         if (!ctx->counts_ev) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->counts_ev, hipEventDisableTiming));
@@ -495,11 +516,14 @@ static int ensure_wave_buffers(rtgl_context *ctx, uint32_t n0, uint32_t max_boun
     }
     const size_t local_px = (size_t)std::max(ctx->local_rows, 1) * ctx->width;
     const bool want_cand = ctx->opt_kernel == RTGL_KERNEL_WAVEFRONT_MFMA_SOLO;
-    if (ctx->wave_capacity < n0 || (multi_sample && !ctx->wave_multi) || (want_cand && !ctx->wave_has_cand)) {
+    const uint32_t need_regions = want_cand ? solo_regions(ctx) : 0u;
+    if (ctx->wave_capacity < n0 || (multi_sample && !ctx->wave_multi) || (want_cand && !ctx->wave_has_cand) || need_regions > ctx->cand_regions) {
         if (ctx->d_wave) { HIPCHK(ctx, hipFree(ctx->d_wave)); ctx->d_wave = nullptr; }
         // per queue: 4 x 16 B + 4 B per ray; per-pixel state for u_samples > 1: 4 x 16 B
         const size_t cand_cap = ctx->opt_kernel == RTGL_KERNEL_WAVEFRONT_MFMA_SOLO ? std::max<size_t>((size_t)n0 * 32, (size_t)1 << 20) : 0;   // pairs of one bounce (8 B each; overflow is tested in place)
-        size_t q_bytes = (size_t)n0 * (68 + 8), bytes = 2 * q_bytes + 1024 + cand_cap * 8 + (multi_sample ? local_px * 64 : 0);
+        const size_t n_regions = std::max<size_t>(need_regions, 4);                                                // one per wave of a scan launch
+        ctx->cand_regions = (uint32_t)n_regions;
+        size_t q_bytes = (size_t)n0 * (68 + 8), bytes = 2 * q_bytes + 1024 + cand_cap * 8 + n_regions * 4 + 256 + (multi_sample ? local_px * 64 : 0);
         HIPCHK(ctx, hipMalloc(&ctx->d_wave, bytes));
         ctx->wave_capacity = n0; ctx->wave_multi = multi_sample; ctx->wave_has_cand = want_cand;
         uint8_t *p = (uint8_t *)ctx->d_wave;
@@ -512,9 +536,11 @@ static int ensure_wave_buffers(rtgl_context *ctx, uint32_t n0, uint32_t max_boun
         for (int q = 0; q < 2; ++q) { ctx->wb.best[q] = (unsigned long long *)p; p += (size_t)n0 * 8; }
         for (int q = 0; q < 2; ++q) { ctx->wb.q[q].pixel = (uint32_t *)p; p += (size_t)n0 * 4; }
         p = (uint8_t *)(((uintptr_t)p + 255) & ~(uintptr_t)255);
-        ctx->wb.cand = (uint2 *)p; p += cand_cap * 8; ctx->wb.cand_capacity = (uint32_t)std::min<size_t>(cand_cap, 0xFFFFFFF0u);
-        // diagnostics: RTGL_DEBUG_CAND_CAP=n pretends the buffer holds n pairs only, so that the in-place fallback of the scan runs
-        if (const char *cc = getenv("RTGL_DEBUG_CAND_CAP")) ctx->wb.cand_capacity = std::min<uint32_t>(ctx->wb.cand_capacity, (uint32_t)atoi(cc));
+        ctx->wb.cand = (uint2 *)p; p += cand_cap * 8; ctx->wb.cand_region = (uint32_t)std::min<size_t>(cand_cap / n_regions, 0xFFFFFFF0u);
+        // diagnostics: RTGL_DEBUG_CAND_CAP=n pretends a wave's region holds n pairs only, so that the in-place fallback of the scan runs
+        if (const char *cc = getenv("RTGL_DEBUG_CAND_CAP")) ctx->wb.cand_region = std::min<uint32_t>(ctx->wb.cand_region, (uint32_t)atoi(cc));
+        p = (uint8_t *)(((uintptr_t)p + 255) & ~(uintptr_t)255);
+        ctx->wb.cand_counts = (uint32_t *)p; p += n_regions * 4;
         p = (uint8_t *)(((uintptr_t)p + 255) & ~(uintptr_t)255);
         if (multi_sample) {
             ctx->wb.sums = (float4 *)p; p += local_px * 16;
@@ -524,7 +550,6 @@ static int ensure_wave_buffers(rtgl_context *ctx, uint32_t n0, uint32_t max_boun
         } else ctx->wb.sums = ctx->wb.cam_a = ctx->wb.cam_b = nullptr, ctx->wb.pix_rng = nullptr;
     }
     ctx->wb.counts = ctx->d_counts;
-    ctx->wb.cand_counts = ctx->d_counts + ctx->counts_capacity;
     ctx->wb.group_bounds = ctx->d_group_bounds;
     return RTGL_OK;
 }
@@ -590,40 +615,51 @@ static void launch_intersect_mfma(rtgl_context *ctx, const SceneView &sc, uint32
 }
 
 // kernel 4: one block per CU (forced by the LDS request), persistent over the ray blocks of its triangle chunk
-static void launch_intersect_solo(rtgl_context *ctx, const SceneView &sc, uint32_t n0, uint32_t bounce)
+#ifndef RTGL_SOLO_CHUNK
+#define RTGL_SOLO_CHUNK 32u      // quads per chunk: <= 128 KB of A tiles in LDS
+#endif
+static uint32_t solo_chunks(const rtgl_context *ctx)
+{
+    const uint32_t n_quads = ctx->n_mf_groups * ctx->mf_group_quads;
+    const uint32_t real_quads = std::min(n_quads, (ctx->n_tri_visits + (uint32_t)kMfQuadTris - 1) / (uint32_t)kMfQuadTris);
+    const uint32_t chunk_quads = std::min(RTGL_SOLO_CHUNK, std::max(real_quads, 1u));
+    return (real_quads + chunk_quads - 1) / chunk_quads;
+}
+
+static int launch_intersect_solo(rtgl_context *ctx, const SceneView &sc, uint32_t n0, uint32_t bounce)
 {
     const uint32_t gq = ctx->mf_group_quads, n_quads = ctx->n_mf_groups * gq;
     const uint32_t real_quads = std::min(n_quads, (ctx->n_tri_visits + (uint32_t)kMfQuadTris - 1) / (uint32_t)kMfQuadTris);
-#ifndef RTGL_SOLO_SETS       // measured on C2: 3 sets 237, 4 sets 255, 5 sets 254, 6 sets 230 (spills), 8 sets 11 Mpaths/s
-#define RTGL_SOLO_SETS 4
-#define RTGL_SOLO_CHUNK 32u
-#endif
-    const uint32_t chunk_quads = std::min(RTGL_SOLO_CHUNK, std::max(real_quads, 1u));             // <= 128 KB of A tiles in LDS
-    const uint32_t chunks = (real_quads + chunk_quads - 1) / chunk_quads;
-    constexpr int kSoloSets = RTGL_SOLO_SETS;                                                     // 32-ray sets per wave: 128 x sets rays per block
-    const uint32_t est = estimate_rays(ctx, n0, bounce), blocks_x_all = (est + 128u * kSoloSets - 1u) / (128u * kSoloSets);
+    const uint32_t chunk_quads = std::min(RTGL_SOLO_CHUNK, std::max(real_quads, 1u));
+    const uint32_t chunks = solo_chunks(ctx);
+    using Cfg = SoloCfg;
+    const uint32_t est = estimate_rays(ctx, n0, bounce), blocks_x_all = (est + Cfg::kRaysPerBlock - 1u) / Cfg::kRaysPerBlock;
     // one block per CU in total: with more, the surplus runs as a second, mostly empty round
     const uint32_t blocks_x = std::max(1u, std::min(blocks_x_all, (uint32_t)ctx->n_cus / chunks));
-    const size_t lds = std::max<size_t>((size_t)chunk_quads * kMfQuadTiles * 1024, 96 * 1024);   // > half of the CU's LDS with the static queue: one block per CU
+    const size_t lds = std::max<size_t>(((size_t)chunk_quads * kMfQuadTiles + 2) * 1024, 96 * 1024);   // + the two rows read a trip ahead behind the last tile; > half of the CU's LDS with the static queue: one block per CU
+#ifdef RT_SOLO_STAMPS
+    if (!ctx->d_dbg_log) { HIPCHK(ctx, hipMalloc((void **)&ctx->d_dbg_log, (size_t)(2 + (2u << 22)) * 4)); HIPCHK(ctx, hipMemsetAsync(ctx->d_dbg_log, 0, 16 * 8 * 64, ctx->stream)); }
+#endif
     MfView mf{ctx->d_mf_groups, ctx->n_mf_groups, gq, n_quads, ctx->d_mf_A, ctx->d_dbg_log, ctx->d_mf_order};
-    static bool attr_set = false;
-    if (!attr_set) {
-        // allow the whole LDS of a CU (160 KB) minus the kernel's static share as dynamic shared memory
-        for (const void *fn : {reinterpret_cast<const void *>(&intersect_mfma_kernel<kSoloSets, false, false, true>),
-                               reinterpret_cast<const void *>(&intersect_mfma_kernel<kSoloSets, true, false, true>)}) {
+    if (!ctx->solo_attr_set) {
+        // allow the whole LDS of a CU (160 KB) minus the kernel's static share as dynamic shared memory.  The attribute belongs to the
+        // (function, device) pair, so it is raised once per context -- a context is bound to one device -- not once per process.
+        for (const void *fn : {reinterpret_cast<const void *>(&scan_solo_kernel<false>),
+                               reinterpret_cast<const void *>(&scan_solo_kernel<true>)}) {
             hipFuncAttributes fattr;
-            if (hipFuncGetAttributes(&fattr, fn) == hipSuccess)
-                (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024 - fattr.sharedSizeBytes));
+            HIPCHK(ctx, hipFuncGetAttributes(&fattr, fn));
+            HIPCHK(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024 - fattr.sharedSizeBytes)));
         }
-        (void)hipGetLastError();
-        attr_set = true;
+        ctx->solo_attr_set = true;
     }
     dim3 grid(blocks_x, chunks);
     if (ctx->opt_counters)
-        hipLaunchKernelGGL((intersect_mfma_kernel<kSoloSets, true, false, true>), grid, dim3(256), lds, ctx->stream, sc, ctx->wb, mf, bounce, chunk_quads, ctx->d_counters, ctx->opt_debug_skip_exact);
+        hipLaunchKernelGGL((scan_solo_kernel<true>), grid, dim3(256), lds, ctx->stream, sc, ctx->wb, mf, bounce, chunk_quads, ctx->d_counters, ctx->opt_debug_skip_exact);
     else
-        hipLaunchKernelGGL((intersect_mfma_kernel<kSoloSets, false, false, true>), grid, dim3(256), lds, ctx->stream, sc, ctx->wb, mf, bounce, chunk_quads, ctx->d_counters, ctx->opt_debug_skip_exact);
-    hipLaunchKernelGGL(narrow_phase_kernel, dim3(2048), dim3(256), 0, ctx->stream, sc, ctx->wb, bounce);
+        hipLaunchKernelGGL((scan_solo_kernel<false>), grid, dim3(256), lds, ctx->stream, sc, ctx->wb, mf, bounce, chunk_quads, ctx->d_counters, ctx->opt_debug_skip_exact);
+    HIPCHK(ctx, hipGetLastError());
+    hipLaunchKernelGGL(narrow_phase_kernel, dim3(blocks_x * chunks * 4u), dim3(256), 0, ctx->stream, sc, ctx->wb, mf, bounce, blocks_x * chunks * 4u);
+    return RTGL_OK;
 }
 
 static int launch_wavefront(rtgl_context *ctx, const SceneView &sc, const FrameParams &P, const ImageView &im, uint32_t n0, uint4 *rng_out)
@@ -636,7 +672,7 @@ static int launch_wavefront(rtgl_context *ctx, const SceneView &sc, const FrameP
         else ctx->est_counts.clear();
     }
     for (uint32_t s = 0; s < P.samples; ++s) {
-        HIPCHK(ctx, hipMemsetAsync(ctx->d_counts, 0, (size_t)ctx->counts_capacity * 2 * sizeof(uint32_t), ctx->stream));
+        HIPCHK(ctx, hipMemsetAsync(ctx->d_counts, 0, counts_bytes(ctx->counts_capacity), ctx->stream));
         hipLaunchKernelGGL(generate_rays_kernel, gen_grid, dim3(256), 0, ctx->stream, P, im, ctx->wb, s, n0,
                            ctx->opt_counters ? ctx->d_counters : (Counters *)nullptr);
         for (uint32_t b = 0; b < P.max_bounce; ++b) {
@@ -644,7 +680,7 @@ static int launch_wavefront(rtgl_context *ctx, const SceneView &sc, const FrameP
             if (ctx->opt_kernel == RTGL_KERNEL_WAVEFRONT_SPLIT || ctx->opt_kernel == RTGL_KERNEL_WAVEFRONT_MFMA || ctx->opt_kernel == RTGL_KERNEL_WAVEFRONT_MFMA_SOLO) {
                 if (sc.n_tri_visits > 0 && ctx->opt_kernel == RTGL_KERNEL_WAVEFRONT_MFMA_SOLO) {
                     kev_mark(ctx);
-                    launch_intersect_solo(ctx, sc, n0, b);
+                    { const int rc = launch_intersect_solo(ctx, sc, n0, b); if (rc) return rc; }
                     kev_mark(ctx);
                 } else if (sc.n_tri_visits > 0 && ctx->opt_kernel == RTGL_KERNEL_WAVEFRONT_MFMA) {
                     kev_mark(ctx);

@@ -84,7 +84,7 @@ def test_needles_and_mixed_scales_in_one_group(rt, oracle, variant):
 def test_candidate_buffer_overflow_falls_back_to_in_place_exact_tests(rt, oracle, monkeypatch):
     """kernel 4 appends survivors to a global buffer for the narrow-phase kernel; pairs that do not fit are tested inside the scan.
     With the buffer clamped to 1000 pairs almost everything takes that path: the result must not change."""
-    monkeypatch.setenv("RTGL_DEBUG_CAND_CAP", "1000")
+    monkeypatch.setenv("RTGL_DEBUG_CAND_CAP", "4")
     sc = rt.scenes
     patch = sc.grid_mesh(4, 3, x0=-12.0, x1=12.0, y0=-10.0, y1=4.0, amp=0.0).reshape(-1, 4)
     v = np.concatenate([patch] * 20 + [sc.grid_mesh(20, 10).reshape(-1, 4)])
