@@ -68,8 +68,8 @@ def cpu_baseline(rt, scene, params, width, height, budget_rows=256):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=400)      # ~2.5 s of timed region on C2: clocks settle, the driver's SMI sampler sees the run
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", default="C2", help="C2 (headline), C4, C5 or C1")
     ap.add_argument("--kernel", type=int, default=None, help="kernel variant override (rtgl_set_option kernel)")
     ap.add_argument("--wf-rays", type=int, default=None, help="rays per lane of the wavefront kernel (1, 2, 4)")
@@ -77,15 +77,13 @@ def main():
     ap.add_argument("--wf-chunk", type=int, default=None, help="triangles per work item of the split intersect kernel")
     ap.add_argument("--wf-early", type=int, default=None, help="leading bounces with the wave-level edge short circuit")
     ap.add_argument("--wf-packed", type=int, default=None, help="v_pk_fma_f32 ray pairs (1) or plain v_fma_f32 (0)")
-    ap.add_argument("--debug-skip-exact", type=int, default=None, help="diagnostic (wrong image): kernel 3 without the exact narrow phase")
-    ap.add_argument("--mf-sets", type=int, default=None, help="kernel 3: 32-ray sets per wave (2 or 4)")
-    ap.add_argument("--mf-chunk-quads", type=int, default=None, help="kernel 3: 40-triangle quads per work item")
-    ap.add_argument("--mf-group-quads", type=int, default=None, help="kernel 3: quads sharing one local origin (1, 2, 4, 8, 16)")
+    ap.add_argument("--debug-skip-exact", type=int, default=None, help="diagnostic (wrong image): 1 drops the broad-phase survivors, 2 lets nothing survive")
+    ap.add_argument("--mf-chunk-quads", type=int, default=None, help="kernel 4: 40-triangle quads per LDS-resident chunk (1..32)")
+    ap.add_argument("--mf-group-quads", type=int, default=None, help="kernel 4: quads sharing one local origin (1, 2, 4 .. 64)")
     ap.add_argument("--debug-bounces", type=int, default=None, help="diagnostic: override the bounce limit of the configuration (not the named workload)")
     ap.add_argument("--strip-rows", type=int, default=8, help="rows per interleaved strip (multiple of 8); 8 balances the ranks to +-3%% at N = 8, 16 to +-6%%")
     ap.add_argument("--timing-period", type=int, default=None, help="frames between kernel-timed frames (default: 1 at N = 1, 4 for N > 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-fast-mode", action="store_true", help="skip the extra (unreported in `value`) measurement of the kernel-3 fast variant")
     ap.add_argument("--sync-each-frame", action="store_true", help="diagnostic: host waits for every frame")
     ap.add_argument("--no-kernel-timing", action="store_true", help="diagnostic: no HIP events around the scan launches")
     ap.add_argument("--cpu-rows", type=int, default=256)
@@ -120,7 +118,7 @@ def main():
     ctx = rt.host.Context(W, H, device=local_rank, rank=rank, world=world, strip_rows=args.strip_rows)
     ctx.upload_scene(scene)
     for key, val in (("kernel", args.kernel), ("wf_rays", args.wf_rays), ("wf_mode", args.wf_mode), ("wf_chunk", args.wf_chunk), ("wf_early", args.wf_early), ("wf_packed", args.wf_packed),
-                     ("mf_sets", args.mf_sets), ("mf_chunk_quads", args.mf_chunk_quads), ("mf_group_quads", args.mf_group_quads), ("debug_skip_exact", args.debug_skip_exact)):
+                     ("mf_chunk_quads", args.mf_chunk_quads), ("mf_group_quads", args.mf_group_quads), ("debug_skip_exact", args.debug_skip_exact)):
         if val is not None:
             ctx.set_option(key, val)
     gat = rt.tiling.FrameGatherer(W, H, rank, world, dev, args.strip_rows)
@@ -197,30 +195,43 @@ def main():
         if scan_launches == 0:            # a scene without triangles has no scan launches: describe the whole frame instead
             launches_per_frame, avg_launch_s, bytes_per_launch = 1, frame_ms / 1e3 / max(timed_frames, 1), alg["total"] * share
         flops_per_launch = cnt["triangle_tests"] * 36.0 * share / launches_per_frame   # 18 fma per edge-function triple
-        kname = {0: "pathtrace_mega_kernel", 1: "bounce_kernel", 2: "intersect_kernel", 3: "intersect_mfma_kernel", 4: "scan_solo_kernel"}[ctx.get_option("kernel_in_use")]
+        kname = {0: "pathtrace_mega_kernel", 1: "bounce_kernel", 2: "intersect_kernel", 4: "scan_solo_kernel"}[ctx.get_option("kernel_in_use")]
         if scan_launches == 0:
             kname = "whole frame (generate_rays + shade)"
         k = ctx.get_option("kernel_in_use")
         gtests = cnt["triangle_tests"] * share / launches_per_frame / avg_launch_s / 1e9
         tflops = flops_per_launch / avg_launch_s / 1e12
-        if k in (3, 4):
-            # bf16 matrix pipe for the conservative broad phase + fp32 VALU for thresholds/minima; both issue from the same
-            # SIMD port and do not overlap (tools/mfma_bf16_valu_rate.hip), so the practical ceiling is the measured issue
-            # floor of "one 32x32x16 MFMA + 5 v_min3 + 2 v_max3" = 22 ns per SIMD per 320 tests
-            floor_gtests = 320.0 / 22.0e-9 * 1024 / 1e9
-            compute = {"pipe": "bf16 MFMA broad phase + fp32 VALU (one issue port per SIMD)", "achieved": tflops, "peak": BF16_DENSE_PEAK_TFLOPS,
-                       "unit": "TFLOP/s", "frac": tflops / BF16_DENSE_PEAK_TFLOPS, "flop_per_test": 36, "gtests_per_s": gtests,
-                       "issue_floor_gtests_per_s": floor_gtests, "frac_of_issue_floor": gtests / floor_gtests,
-                       "scan_share_of_frame": scan_ms / max(frame_ms, 1e-9)}
+        hbm = {"achieved": bytes_per_launch / avg_launch_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+               "frac": bytes_per_launch / avg_launch_s / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": bytes_per_launch,
+               "note": "SURVEY 8(d3) accounting: one scene stream per 256 live rays per bounce; the scene lives in L2/LDS, so this fraction is small by construction"}
+        traffic, traffic_src = None, None
+        tf = os.path.join(ROOT, "profiles", "hbm_traffic.json")     # written by tools/diagnostics/gpu_profile.sh (rocprofv3 PMC passes), keyed "<config>/<kernel>"
+        if os.path.exists(tf) and world == 1:
+            ent = json.load(open(tf)).get(f"{args.config}/{kname}")
+            if ent:
+                traffic, traffic_src = ent["hbm_bytes_per_launch"], f"committed rocprofv3 PMC profile ({ent.get('profile', 'profiles/')}), not measured in this run"
+        if k == 4:
+            # The dominant kernel issues one v_mfma_f32_32x32x16_bf16 (32,768 flop) per 320 ray x triangle tests (10 triangles x 32
+            # rays) plus 8 VALU instructions examining its 16 results.  Matrix and vector instructions share the SIMD's issue port:
+            # the bound is matrix/vector ISSUE, priced against the dense bf16 MFMA peak (one such MFMA per 32 cycles per SIMD).
+            n_simd, clk = 1024.0, 2.4e9
+            products_per_launch = cnt["triangle_tests"] * share / launches_per_frame / 320.0
+            mfma_tflops = products_per_launch * 32768.0 / avg_launch_s / 1e12
+            roof = {"bound": "mfma", "achieved": mfma_tflops, "peak": BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": mfma_tflops / BF16_DENSE_PEAK_TFLOPS,
+                    "traffic": traffic, "traffic_source": traffic_src, "kernel": kname, "launches_per_frame": launches_per_frame, "avg_launch_ms": avg_launch_s * 1e3,
+                    "products_per_launch": products_per_launch, "cycles_per_product": n_simd * clk * avg_launch_s / max(products_per_launch, 1.0),
+                    "frac_of_mfma_issue_peak": products_per_launch / avg_launch_s / (n_simd * clk / 32.0),
+                    "issue_floor_cycles_per_product": 44.0,
+                    "note": "bound = matrix/vector issue of one SIMD port: 32 cycles of matrix pipe per product, 44 cycles of issue (MFMA 8 + 9 VALU x 4) measured "
+                            "for the bare instruction stream (tools/scan_stage_rate.hip); cycles are counted at the nominal 2.4 GHz, the chip runs this loop at ~2.0-2.1 GHz",
+                    "hbm": hbm}
+            compute = {"pipe": "bf16 MFMA broad phase + fp32 VALU examination (one issue port per SIMD)", "algorithmic_tflops": tflops, "flop_per_test": 36,
+                       "gtests_per_s": gtests, "scan_share_of_frame": scan_ms / max(frame_ms, 1e-9)}
         else:
+            roof = {"bound": "hbm", "traffic": traffic, "traffic_source": traffic_src, "kernel": kname, "launches_per_frame": launches_per_frame,
+                    "avg_launch_ms": avg_launch_s * 1e3, **hbm}
             compute = {"pipe": "fp32 VALU", "achieved": tflops, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / FP32_PEAK_TFLOPS,
                        "flop_per_test": 36, "gtests_per_s": gtests, "scan_share_of_frame": scan_ms / max(frame_ms, 1e-9)}
-        traffic = None
-        tf = os.path.join(ROOT, "profiles", "hbm_traffic.json")     # written by scripts/gpu_profile.sh (rocprofv3 PMC passes)
-        if os.path.exists(tf):
-            tj = json.load(open(tf))
-            if tj.get("kernel") == kname and tj.get("config") == args.config and world == 1:
-                traffic = tj["hbm_bytes_per_launch"]
         out = {
             "metric": "Mpaths/s at 1920x1080, 8 bounces, 10k tris" if args.config == "C2" else f"Mpaths/s ({args.config})",
             "value": paths / dt / 1e6, "unit": "Mpaths/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -232,31 +243,22 @@ def main():
                        "parallelism": f"{world} GPU(s), {args.strip_rows}-row strips interleaved, gather to rank 0 every frame" + (" (asynchronous, overlapped with the next frame)" if world > 1 else ""),
                        "kernel": ctx.get_option("kernel_in_use"), "wf_rays": ctx.get_option("wf_rays"), "wf_mode": ctx.get_option("wf_mode"), "wf_chunk": ctx.get_option("wf_chunk"), "wf_early": ctx.get_option("wf_early"), "wf_packed": ctx.get_option("wf_packed"),
                        "mf_sets": ctx.get_option("mf_sets"), "mf_group_quads": ctx.get_option("mf_group_quads"), "mf_chunk_quads": ctx.get_option("mf_chunk_quads")},
-            "roofline": {"bound": "hbm", "achieved": bytes_per_launch / avg_launch_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": bytes_per_launch / avg_launch_s / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": kname, "launches_per_frame": launches_per_frame, "avg_launch_ms": avg_launch_s * 1e3,
-                         "algorithmic_bytes_per_launch": bytes_per_launch,
-                         "note": "brute-force ray x triangle scan is bound by vector/matrix issue, not memory (see compute); HBM fraction is small by construction"},
+            "roofline": roof,
             "compute": compute,
             "counters_per_frame": cnt,
         }
-        if world == 1 and ctx.get_option("kernel_in_use") == 4 and args.kernel is None and not args.no_fast_mode:
-            # not part of `value`: the same frames with the three-waves-per-SIMD scan (kernel 3), the fast variant that is NOT the
-            # default because of the rare cross-wave fault described in DESIGN.md section 5
-            ctx.set_option("kernel", 3)
-            ctx.set_option("kernel_timing", 0)
-            for p in timed[:3]:
-                ctx.render(p, sync=False)
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for p in timed:
-                ctx.render(p, sync=False)
-            torch.cuda.synchronize()
-            out["fast_mode"] = {"kernel": 3, "value": paths / (time.perf_counter() - t1) / 1e6, "unit": "Mpaths/s",
-                                "note": "opt-in (RTGL_AMD_KERNEL=3): three waves per SIMD; bit-identical in every soak of this build, but see DESIGN.md section 5"}
-            ctx.set_option("kernel", 4)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(rt, scene, timed[0], W, H, args.cpu_rows)
+            # the reference itself cannot travel to the GPU box: its llvmpipe timing is measured in the build container by
+            # oracle/time_reference.py and carried here as a second, stated baseline
+            rf = os.path.join(ROOT, "profiles", "llvmpipe_reference_timing.json")
+            if os.path.exists(rf):
+                rj = json.load(open(rf))
+                pick = [c for c in rj["cases"] if c["case"].startswith("C2" if args.config != "C1" else "C1:")]
+                out["cpu_baseline_reference"] = {
+                    "kind": "reference", "unit": "Mpaths/s", "cores": rj["cores"], "renderer": rj["renderer"], "measured_in": rj["measured_in"],
+                    "value": max(c["reference_llvmpipe_mpaths_per_s"] for c in pick) if pick else None,
+                    "cases": {c["case"]: round(c["reference_llvmpipe_mpaths_per_s"], 5) for c in pick}, "note": rj["note"]}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -8,6 +8,7 @@
 #pragma once
 #include <algorithm>
 #include <limits>
+#include <ostream>
 #include <vector>
 
 #include "glm_shim.h"
@@ -25,6 +26,13 @@ inline bool intersect(const AABB *a, const AABB *b)
     return true;
 }
 
+// stream form of the reference (src/kdtree.h:56-60); its main() prints nodes this way (src/main.cpp:165)
+inline std::ostream &operator<<(std::ostream &os, const AABB &obj)
+{
+    os << "AABB { min = " << obj.min << ", max = " << obj.max << " }";
+    return os;
+}
+
 struct KdNode : public AABB
 {
     uint left = INVALID;
@@ -32,6 +40,13 @@ struct KdNode : public AABB
     uint offset = 0;
     uint count = 0;
 };
+
+// src/kdtree.h:71-75
+inline std::ostream &operator<<(std::ostream &os, const KdNode &obj)
+{
+    os << "Node { l = " << obj.left << ", r = " << obj.right << ", o = " << obj.offset << ", c = " << obj.count << " }";
+    return os;
+}
 static_assert(sizeof(KdNode) == 48, "KdNode must match the shader's Node (std430, 48 bytes)");
 
 template <class Bounded, uint NODE_SIZE = 8, uint MAX_DEPTH = 5>

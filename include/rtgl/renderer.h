@@ -55,6 +55,13 @@ struct alignas(16) Sphere {
 };
 static_assert(sizeof(Sphere) == 32, "Sphere stride (std140, shaders/raytracer.glsl:11-15)");
 
+// stream form of the reference (src/renderer.h:64-68)
+inline std::ostream &operator<<(std::ostream &os, const Sphere &obj)
+{
+    os << "Sphere { c = " << obj.center << ", r = " << obj.radius << " }";
+    return os;
+}
+
 enum MaterialType : unsigned int { DIFFUSE = 0, SPECULAR = 1, TRANSMISSIVE = 2 };
 
 struct alignas(16) Material {

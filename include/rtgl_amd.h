@@ -67,17 +67,17 @@ typedef struct rtgl_counters {
     uint64_t reserved[3];
 } rtgl_counters;
 
-/* Kernel variants (rtgl_set_option "kernel"; the environment variable RTGL_AMD_KERNEL=0..3 changes the default of new
+/* Kernel variants (rtgl_set_option "kernel"; the environment variable RTGL_AMD_KERNEL=0, 1, 2 or 4 changes the default of new
  * contexts).  All produce bit-identical images.  Unless a variant was requested explicitly, a scene without triangles is rendered
  * with RTGL_KERNEL_MEGA (there is no scan to split off; one launch per frame). */
 enum {
     RTGL_KERNEL_MEGA = 0,            /* one launch per frame, one lane per pixel, whole path in registers */
     RTGL_KERNEL_WAVEFRONT = 1,       /* one fused launch per bounce over the compacted ray queue */
     RTGL_KERNEL_WAVEFRONT_SPLIT = 2, /* per bounce: intersect (ray blocks x triangle chunks, fp32 VALU filter) + shade */
-    RTGL_KERNEL_WAVEFRONT_MFMA = 3,  /* as 2, with a conservative bf16 matrix-core broad phase in front of the exact test, 3 waves per SIMD: the
-                                      * fastest variant, but see DESIGN.md section 5 (a rare cross-wave fault; opt-in) */
-    RTGL_KERNEL_WAVEFRONT_MFMA_SOLO = 4 /* default: as 3 with one wave per SIMD: persistent blocks, A tiles in LDS, examination interleaved with the
-                                         * matrix instructions, exact tests in a separate narrow-phase kernel */
+    RTGL_KERNEL_REMOVED_3 = 3,       /* (round 1's three-waves-per-SIMD matrix-core scan: not deterministic, removed; refused) */
+    RTGL_KERNEL_WAVEFRONT_MFMA_SOLO = 4 /* default: as 2, with a conservative bf16 matrix-core broad phase in front of the exact test: one wave
+                                         * per SIMD, persistent blocks, A tiles in LDS, hand-ordered instruction stream, exact tests in a
+                                         * separate narrow-phase kernel */
 };
 
 /* -- lifetime: replaces Renderer::Renderer(width,height) GL object creation (src/renderer.cpp:21-64).
@@ -135,8 +135,8 @@ int rtgl_get_counters(rtgl_context *ctx, rtgl_counters *out);  /* synchronises *
 int rtgl_read_rng_state(rtgl_context *ctx, uint32_t *xyzw);    /* per local pixel final PCG4D state of the last frame; needs option "rng_state"=1 */
 /* keys: "kernel" (enum above), "wf_rays" (rays per lane 1/2/4/8), "wf_mode" (0 scalar-fed, 1 LDS tiles),
  * "wf_chunk" (triangles per work item of the split intersect kernel, multiple of 64), "wf_early" (leading bounces
- * that use the wave-level edge short circuit), "wf_packed" (v_pk_fma_f32 ray pairs on/off), "mf_sets" (32-ray sets
- * per wave of the kernel-3 scan: 2), "mf_chunk_quads" (40-triangle quads per work item), "mf_group_quads" (quads
+ * that use the wave-level edge short circuit), "wf_packed" (v_pk_fma_f32 ray pairs on/off), "mf_chunk_quads" (kernel 4: 40-triangle quads
+ * per work item = per block's LDS-resident chunk, 1..32), "mf_group_quads" (quads
  * sharing one local origin: a power of two up to 64; changing it rebuilds the broad-phase data at the next frame),
  * "rng_state", "counters", "kernel_timing" (0 off; N > 0: every N-th frame since the last rtgl_timing_reset carries HIP
  * event pairs around its dominant-kernel launches) */

@@ -211,7 +211,7 @@ scan_solo_kernel(SceneView sc, WaveBuffers wb, MfView mf, uint32_t bounce, uint3
             // exceed 2^32 pairs per wave.
             for (uint32_t i = (uint32_t)lane; i < qn; i += 64u) {
                 const uint32_t e = queue[i], pos = v_chunk_begin + (e & 0xffffu);
-                const bool real = pos < v_chunk_end && (debug_skip_exact == 0 || debug_skip_exact >= 4);
+                const bool real = pos < v_chunk_end && debug_skip_exact == 0;
                 const uint32_t slot = wave_slot0 + (e >> 16);
                 if (appended + i < (unsigned long long)wb.cand_region) cand[appended + i] = make_uint2(real ? slot : 0xFFFFFFFFu, pos);
                 else if (real) exact_and_merge(sc, qin, best, slot, mf.order[pos]);

@@ -195,7 +195,7 @@ struct rtgl_context {
     bool tris_dirty = false, visits_dirty = false;
     FrameParams params{};
     bool have_params = false;
-    int opt_kernel = RTGL_KERNEL_WAVEFRONT_MFMA_SOLO, opt_rng_state = 0, opt_counters = 0, opt_kernel_timing = 0, opt_wf_rays = 4, opt_wf_mode = kLds, opt_wf_chunk = 256, opt_wf_early = 0, opt_wf_packed = 0, opt_mf_sets = 2, opt_mf_chunk_quads = 64, opt_mf_group_quads = 32, opt_debug_skip_exact = 0;
+    int opt_kernel = RTGL_KERNEL_WAVEFRONT_MFMA_SOLO, opt_rng_state = 0, opt_counters = 0, opt_kernel_timing = 0, opt_wf_rays = 4, opt_wf_mode = kLds, opt_wf_chunk = 256, opt_wf_early = 0, opt_wf_packed = 0, opt_mf_chunk_quads = 32, opt_mf_group_quads = 32, opt_debug_skip_exact = 0;
 };
 
 static int fail(rtgl_context *ctx, int code, const std::string &msg)
@@ -251,12 +251,12 @@ extern "C" int rtgl_create_tiled(rtgl_context **out, int width, int height, int 
     CCHK(hipMalloc((void **)&ctx->d_image_own, img_bytes));
     CCHK(hipMemsetAsync(ctx->d_image_own, 0, img_bytes, ctx->stream));
     ctx->d_image = ctx->d_image_own;
-    CCHK(hipMalloc((void **)&ctx->d_counters, 64 + sizeof(MfVerifyLog)));      // counters, then the kernel-3 verification log
-    CCHK(hipMemsetAsync(ctx->d_counters, 0, 64 + sizeof(MfVerifyLog), ctx->stream));
+    CCHK(hipMalloc((void **)&ctx->d_counters, 64));
+    CCHK(hipMemsetAsync(ctx->d_counters, 0, 64, ctx->stream));
     CCHK(hipStreamSynchronize(ctx->stream));
 #undef CCHK
-    // operational override of the default scan without touching the caller: RTGL_AMD_KERNEL=0..3 (rtgl_set_option still wins)
-    if (const char *k = getenv("RTGL_AMD_KERNEL")) { const int v = atoi(k); if (v >= RTGL_KERNEL_MEGA && v <= RTGL_KERNEL_WAVEFRONT_MFMA_SOLO) { ctx->opt_kernel = v; ctx->kernel_explicit = true; } }
+    // operational override of the default scan without touching the caller: RTGL_AMD_KERNEL=0, 1, 2 or 4 (rtgl_set_option still wins)
+    if (const char *k = getenv("RTGL_AMD_KERNEL")) { const int v = atoi(k); if (v >= RTGL_KERNEL_MEGA && v <= RTGL_KERNEL_WAVEFRONT_MFMA_SOLO && v != RTGL_KERNEL_REMOVED_3) { ctx->opt_kernel = v; ctx->kernel_explicit = true; } }
     *out = ctx;
     return RTGL_OK;
 }
@@ -476,7 +476,7 @@ static int rebuild_triangles(rtgl_context *ctx)
         HIPCHK(ctx, hipMemcpyAsync(ctx->d_mf_order, order.data(), order.size() * 4, hipMemcpyHostToDevice, ctx->stream));
         HIPCHK(ctx, hipMalloc((void **)&ctx->d_mf_groups, (size_t)ctx->n_mf_groups * sizeof(MfGroup)));
         const size_t a_bytes = ((size_t)ctx->n_mf_groups * ctx->mf_group_quads + 1) * kMfQuadTiles * 64 * sizeof(uint4);   // two K panels per tile; + one zero quad
-        if (a_bytes > 0xFFFF0000ull) return fail(ctx, RTGL_ERR_INVALID, "mesh too large for the 32-bit tile offsets of the kernel-3 scan");
+        if (a_bytes > 0xFFFF0000ull) return fail(ctx, RTGL_ERR_INVALID, "mesh too large for the 32-bit tile offsets of the matrix-core scan");
         HIPCHK(ctx, hipMalloc((void **)&ctx->d_mf_A, a_bytes));
         HIPCHK(ctx, hipMemsetAsync(ctx->d_mf_A, 0, a_bytes, ctx->stream));
         hipLaunchKernelGGL(prepare_mfma_kernel, dim3(ctx->n_mf_groups), dim3(64), 0, ctx->stream, ctx->d_vertices, d_visit,
@@ -587,42 +587,12 @@ static void launch_intersect(rtgl_context *ctx, const SceneView &sc, uint32_t n0
 #undef RTGL_LAUNCH_ISECT
 }
 
-template <int S>
-static void launch_intersect_mfma(rtgl_context *ctx, const SceneView &sc, uint32_t n0, uint32_t bounce)
-{
-    const uint32_t gq = ctx->mf_group_quads, n_quads = ctx->n_mf_groups * gq;
-    uint32_t chunk_quads = std::min((uint32_t)ctx->opt_mf_chunk_quads, kMfMaxChunkQuads);
-    const uint32_t est = estimate_rays(ctx, n0, bounce), rays_per_block = 4u * S * 32u;
-    const uint32_t blocks_x = (est + rays_per_block - 1) / rays_per_block;
-    // late bounces have few rays: split the triangle range finer (down to 8 quads, also inside a group) so that the launch
-    // still fills the chip and each block's serial share stays short
-    const uint32_t real_quads = std::min(n_quads, (ctx->n_tri_visits + (uint32_t)kMfQuadTris - 1) / (uint32_t)kMfQuadTris);
-    while (chunk_quads > 8u && (uint64_t)blocks_x * ((real_quads + chunk_quads - 1) / chunk_quads) < 4096u) chunk_quads /= 2u;
-    dim3 grid(blocks_x, (real_quads + chunk_quads - 1) / chunk_quads);
-    if ((ctx->opt_debug_skip_exact == 4 || ctx->opt_debug_skip_exact == 5) && !ctx->d_dbg_log) {
-        (void)hipMalloc((void **)&ctx->d_dbg_log, (size_t)(2 + (2u << 22)) * 4);
-        (void)hipMemsetAsync(ctx->d_dbg_log, 0, 32, ctx->stream);
-    }
-    MfView mf{ctx->d_mf_groups, ctx->n_mf_groups, gq, n_quads, ctx->d_mf_A, ctx->d_dbg_log, ctx->d_mf_order};
-    // diagnostics: RTGL_DEBUG_LDS_PAD=bytes of unused dynamic LDS per block limits the blocks per CU (60000 -> one wave per SIMD)
-    const size_t lds_pad = getenv("RTGL_DEBUG_LDS_PAD") ? (size_t)atoi(getenv("RTGL_DEBUG_LDS_PAD")) : 0;
-    if (ctx->opt_debug_skip_exact == 3)
-        hipLaunchKernelGGL((intersect_mfma_kernel<2, true, true>), dim3((est + 255) / 256, grid.y), dim3(256), 0, ctx->stream, sc, ctx->wb, mf, bounce, chunk_quads, ctx->d_counters, 0);
-    else if (ctx->opt_counters)
-        hipLaunchKernelGGL((intersect_mfma_kernel<S, true>), grid, dim3(256), lds_pad, ctx->stream, sc, ctx->wb, mf, bounce, chunk_quads, ctx->d_counters, ctx->opt_debug_skip_exact);
-    else
-        hipLaunchKernelGGL((intersect_mfma_kernel<S, false>), grid, dim3(256), lds_pad, ctx->stream, sc, ctx->wb, mf, bounce, chunk_quads, ctx->d_counters, ctx->opt_debug_skip_exact);
-}
-
 // kernel 4: one block per CU (forced by the LDS request), persistent over the ray blocks of its triangle chunk
-#ifndef RTGL_SOLO_CHUNK
-#define RTGL_SOLO_CHUNK 32u      // quads per chunk: <= 128 KB of A tiles in LDS
-#endif
 static uint32_t solo_chunks(const rtgl_context *ctx)
 {
     const uint32_t n_quads = ctx->n_mf_groups * ctx->mf_group_quads;
     const uint32_t real_quads = std::min(n_quads, (ctx->n_tri_visits + (uint32_t)kMfQuadTris - 1) / (uint32_t)kMfQuadTris);
-    const uint32_t chunk_quads = std::min(RTGL_SOLO_CHUNK, std::max(real_quads, 1u));
+    const uint32_t chunk_quads = std::min((uint32_t)ctx->opt_mf_chunk_quads, std::max(real_quads, 1u));
     return (real_quads + chunk_quads - 1) / chunk_quads;
 }
 
@@ -630,7 +600,7 @@ static int launch_intersect_solo(rtgl_context *ctx, const SceneView &sc, uint32_
 {
     const uint32_t gq = ctx->mf_group_quads, n_quads = ctx->n_mf_groups * gq;
     const uint32_t real_quads = std::min(n_quads, (ctx->n_tri_visits + (uint32_t)kMfQuadTris - 1) / (uint32_t)kMfQuadTris);
-    const uint32_t chunk_quads = std::min(RTGL_SOLO_CHUNK, std::max(real_quads, 1u));
+    const uint32_t chunk_quads = std::min((uint32_t)ctx->opt_mf_chunk_quads, std::max(real_quads, 1u));
     const uint32_t chunks = solo_chunks(ctx);
     using Cfg = SoloCfg;
     const uint32_t est = estimate_rays(ctx, n0, bounce), blocks_x_all = (est + Cfg::kRaysPerBlock - 1u) / Cfg::kRaysPerBlock;
@@ -677,14 +647,10 @@ static int launch_wavefront(rtgl_context *ctx, const SceneView &sc, const FrameP
                            ctx->opt_counters ? ctx->d_counters : (Counters *)nullptr);
         for (uint32_t b = 0; b < P.max_bounce; ++b) {
             const int key = ctx->opt_wf_mode * 10 + ctx->opt_wf_rays;
-            if (ctx->opt_kernel == RTGL_KERNEL_WAVEFRONT_SPLIT || ctx->opt_kernel == RTGL_KERNEL_WAVEFRONT_MFMA || ctx->opt_kernel == RTGL_KERNEL_WAVEFRONT_MFMA_SOLO) {
+            if (ctx->opt_kernel == RTGL_KERNEL_WAVEFRONT_SPLIT || ctx->opt_kernel == RTGL_KERNEL_WAVEFRONT_MFMA_SOLO) {
                 if (sc.n_tri_visits > 0 && ctx->opt_kernel == RTGL_KERNEL_WAVEFRONT_MFMA_SOLO) {
                     kev_mark(ctx);
                     { const int rc = launch_intersect_solo(ctx, sc, n0, b); if (rc) return rc; }
-                    kev_mark(ctx);
-                } else if (sc.n_tri_visits > 0 && ctx->opt_kernel == RTGL_KERNEL_WAVEFRONT_MFMA) {
-                    kev_mark(ctx);
-                    launch_intersect_mfma<2>(ctx, sc, n0, b);
                     kev_mark(ctx);
                 } else if (sc.n_tri_visits > 0) {
                     kev_mark(ctx);
@@ -945,29 +911,6 @@ extern "C" int rtgl_get_counters(rtgl_context *ctx, rtgl_counters *out)
     memset(out, 0, sizeof *out);
     out->paths = c.paths; out->segments = c.segments; out->triangle_tests = c.tri_tests;
     out->candidates = c.candidates; out->env_lookups = c.env_lookups;
-    if (ctx->opt_debug_skip_exact == 4 && ctx->d_dbg_log && getenv("RTGL_DEBUG_DUMP")) {      // survivor log -> file, then reset
-        std::vector<uint32_t> h(2 + (2u << 22));
-        HIPCHK(ctx, hipMemcpy(h.data(), ctx->d_dbg_log, h.size() * 4, hipMemcpyDeviceToHost));
-        if (FILE *f = fopen(getenv("RTGL_DEBUG_DUMP"), "ab")) { const uint32_t n = std::min(h[0], 1u << 22); fwrite(&n, 4, 1, f); fwrite(h.data() + 2, 8, n, f); fclose(f); }
-        HIPCHK(ctx, hipMemset(ctx->d_dbg_log, 0, 8));
-    }
-    if (ctx->opt_debug_skip_exact == 5 && ctx->d_dbg_log) {      // checksum of every examined minimum (builds with -DMF_CHECKSUM)
-        unsigned long long h[4];
-        HIPCHK(ctx, hipMemcpy(h, ctx->d_dbg_log, sizeof h, hipMemcpyDeviceToHost));
-        fprintf(stderr, "rtgl checksum: minima %016llx  lanes-with-survivor %llu\n", h[1], h[2]);
-        HIPCHK(ctx, hipMemset(ctx->d_dbg_log, 0, 32));
-    }
-    if (ctx->opt_debug_skip_exact == 3) {          // kernel-3 verification log: pairs the broad phase rejected but the exact test accepts
-        static MfVerifyLog log;
-        HIPCHK(ctx, hipMemcpy(&log, reinterpret_cast<char *>(ctx->d_counters) + 64, sizeof log, hipMemcpyDeviceToHost));
-        fprintf(stderr, "rtgl verify: %u false rejections\n", log.n);
-        for (uint32_t i = 0; i < std::min(log.n, 64u); ++i) {
-            const float *e = log.ev[i];
-            fprintf(stderr, "  slot %.0f visit %.0f pos %.0f group %.0f bounce %.0f  F~ %.9g %.9g %.9g  thresh %.9g  o %.9g %.9g %.9g  d %.9g %.9g %.9g  t %.9g\n",
-                    e[0], e[1], e[2], e[3], e[15], e[4], e[5], e[6], e[7], e[8], e[9], e[10], e[11], e[12], e[13], e[14]);
-        }
-        out->reserved[0] = log.n;
-    }
     return RTGL_OK;
 }
 
@@ -986,6 +929,8 @@ extern "C" int rtgl_set_option(rtgl_context *ctx, const char *key, int value)
     ENTER(ctx);
     if (!key) return fail(ctx, RTGL_ERR_INVALID, "key is NULL");
     if (!strcmp(key, "kernel")) {
+        if (value == RTGL_KERNEL_REMOVED_3)
+            return fail(ctx, RTGL_ERR_INVALID, "kernel variant 3 (three waves per SIMD) was removed: it was not deterministic (DESIGN.md section 5); use 4");
         if (value < RTGL_KERNEL_MEGA || value > RTGL_KERNEL_WAVEFRONT_MFMA_SOLO)
             return fail(ctx, RTGL_ERR_INVALID, "unknown kernel variant");
         ctx->opt_kernel = value; ctx->kernel_explicit = true;
@@ -996,12 +941,10 @@ extern "C" int rtgl_set_option(rtgl_context *ctx, const char *key, int value)
         if (value < kBoundGroup || value % kBoundGroup || (uint32_t)value > kMaxChunk) return fail(ctx, RTGL_ERR_INVALID, "wf_chunk must be a multiple of 64 in [64, 4096]");
         ctx->opt_wf_chunk = value;
     } else if (!strcmp(key, "debug_skip_exact")) {      // timing diagnostics only: the image is wrong
-        ctx->opt_debug_skip_exact = value;               // 1: no exact narrow phase; 2: broad phase rejects everything
-    } else if (!strcmp(key, "mf_sets")) {
-        if (value != 2) return fail(ctx, RTGL_ERR_INVALID, "mf_sets must be 2 (4 sets per wave were measured 10% slower and removed)");
-        ctx->opt_mf_sets = value;
+        if (value < 0 || value > 2) return fail(ctx, RTGL_ERR_INVALID, "debug_skip_exact must be 0, 1 or 2");
+        ctx->opt_debug_skip_exact = value;               // 1: survivors are dropped instead of tested; 2: broad phase rejects everything
     } else if (!strcmp(key, "mf_chunk_quads")) {
-        if (value < 1 || (uint32_t)value > kMfMaxChunkQuads) return fail(ctx, RTGL_ERR_INVALID, "mf_chunk_quads must be in [1, 128]");
+        if (value < 1 || (uint32_t)value > kMfMaxChunkQuads) return fail(ctx, RTGL_ERR_INVALID, "mf_chunk_quads must be in [1, 32]");
         ctx->opt_mf_chunk_quads = value;
     } else if (!strcmp(key, "mf_group_quads")) {
         if (value < 1 || value > (int)kMfMaxGroupQuads || (value & (value - 1))) return fail(ctx, RTGL_ERR_INVALID, "mf_group_quads must be a power of two in [1, 64]");
@@ -1036,7 +979,7 @@ extern "C" int rtgl_get_option(rtgl_context *ctx, const char *key, int *value)
     else if (!strcmp(key, "wf_chunk")) *value = ctx->opt_wf_chunk;
     else if (!strcmp(key, "wf_early")) *value = ctx->opt_wf_early;
     else if (!strcmp(key, "wf_packed")) *value = ctx->opt_wf_packed;
-    else if (!strcmp(key, "mf_sets")) *value = ctx->opt_mf_sets;
+    else if (!strcmp(key, "mf_sets")) *value = kSoloSets;
     else if (!strcmp(key, "mf_chunk_quads")) *value = ctx->opt_mf_chunk_quads;
     else if (!strcmp(key, "mf_group_quads")) *value = ctx->opt_mf_group_quads;
     else if (!strcmp(key, "rng_state")) *value = ctx->opt_rng_state;

@@ -62,7 +62,9 @@ def build_library(force: bool = False) -> str:
     srcs.append(os.path.join(PKG_DIR, "..", "include", "rtgl_amd.h"))
     stale = not os.path.exists(LIB_PATH) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
     if force or stale:
-        subprocess.check_call(["make", "-s", "-C", CSRC_DIR, "all"])
+        # -B: `force` really recompiles (a library newer than its sources would otherwise make `make all` a no-op and a
+        # stale binary could travel to the GPU box)
+        subprocess.check_call(["make", "-s", "-C", CSRC_DIR] + (["-B"] if force else []) + ["all"])
     return LIB_PATH
 
 

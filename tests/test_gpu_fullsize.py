@@ -52,18 +52,16 @@ def test_c2_counters(c2_reference_image, rt):
     assert np.isfinite(img).all() and (img[..., 3] == 1.0).all()
 
 
-@pytest.mark.parametrize("variant", [(0, 0, 1, 1024), (1, 1, 2, 1024), (2, 0, 2, 512), (2, 1, 8, 256), (2, 1, 1, 2560), (3, 4, 2, 64), (3, 1, 2, 16), (3, 64, 2, 32), (4, 32, 2, 64), (4, 4, 2, 64)])
+@pytest.mark.parametrize("variant", [(0, 0, 1, 1024), (1, 1, 2, 1024), (2, 0, 2, 512), (2, 1, 8, 256), (2, 1, 1, 2560), (4, 32, 2, 32), (4, 4, 2, 32), (4, 1, 2, 7), (4, 64, 2, 20)])
 def test_c2_all_kernel_variants_identical(variant, c2_reference_image, rt):
     base = c2_reference_image[0]
-    if variant[0] in (3, 4):
-        opts = (("kernel", variant[0]), ("mf_group_quads", variant[1]), ("mf_sets", variant[2]), ("mf_chunk_quads", variant[3]))
+    if variant[0] == 4:
+        opts = (("kernel", 4), ("mf_group_quads", variant[1]), ("mf_chunk_quads", variant[3]))
     else:
         opts = (("kernel", variant[0]), ("wf_mode", variant[1]), ("wf_rays", variant[2]), ("wf_chunk", variant[3]))
     img = render(rt, "C2", frames=2, options=opts)[0]
     neq = int((img.view(np.uint32) != base.view(np.uint32)).any(axis=2).sum())
-    # kernel 3 (three waves per SIMD) is subject to the rare cross-wave fault of DESIGN.md section 5: a handful of pixels may lose
-    # or gain a hit in a full-size frame; every other variant must be bit-identical
-    assert neq <= (16 if variant[0] == 3 else 0), f"{neq} pixels differ"
+    assert neq == 0, f"{neq} pixels differ"
 
 
 def test_c2_strips_match_oracle(c2_reference_image, rt, oracle):
@@ -116,9 +114,8 @@ def test_c5_2160p_16_bounces_wide_dof(rt, oracle):
 
 def test_c2_matrix_core_scan_repeats_itself_and_matches_fp32_scan(rt):
     """The default scan (kernel 4, one wave per SIMD) must be run-to-run deterministic (survivor counts included) and agree with
-    the fp32 scan over several accumulated frames.  Kernel 3 (three waves per SIMD) is the variant in which a cross-wave fault
-    loses or invents survivors a few times per 10^8..10^11 tiles depending on the exact code: for it the
-    test only bounds the damage."""
+    the fp32 scan over several accumulated frames.  (Round 1's three-waves-per-SIMD variant lost or invented survivors a few
+    times per 10^8..10^11 tiles; it was removed and this test is the guard against a relapse.)"""
     sc = rt.scenes
     cfg = sc.CONFIGS["C2"]
     scene = cfg["scene"]()
@@ -144,5 +141,42 @@ def test_c2_matrix_core_scan_repeats_itself_and_matches_fp32_scan(rt):
         assert c1 == c2
         for img in (i1, i2):
             assert (img.view(np.uint32) == ref.view(np.uint32)).all()
-    c3, i3 = run((("kernel", 3),))
-    assert int((i3.view(np.uint32) != ref.view(np.uint32)).any(axis=2).sum()) <= 16
+
+
+def test_removed_three_waves_variant_is_refused(rt):
+    """Round 1's kernel 3 (three waves per SIMD) was not deterministic and is gone: asking for it must fail loudly, not fall back."""
+    ctx = rt.host.Context(64, 64)
+    with pytest.raises(rt.host.RtglError):
+        ctx.set_option("kernel", 3)
+    assert ctx.get_option("kernel") == 4
+    ctx.close()
+
+
+def test_c2_degenerate_group_floods_the_candidate_regions(rt, monkeypatch):
+    """One NaN vertex in the C2 mesh makes the bounds of its group NaN: every (ray, triangle) pair of that group survives the broad
+    phase by design (tens of millions of pairs per bounce).  With the per-wave candidate regions clamped to 1000 pairs nearly all of
+    them take the in-place exact test inside the scan; the image must still equal the fp32 scan's, bit for bit."""
+    sc = rt.scenes
+    cfg = sc.CONFIGS["C2"]
+    scene = cfg["scene"]()
+    v = scene.vertices.copy()
+    v[3 * 4321 + 1, 0] = np.nan
+    scene = sc.Scene(spheres=scene.spheres, materials=scene.materials, meshes=scene.meshes, vertices=v, nodes=scene.nodes, env=scene.env)
+    p = cfg["params"]().replace(frames=1, random=sc.GlibcRand(0).rand(), max_bounce=2)
+
+    def run(opts):
+        ctx = rt.host.Context(cfg["width"], cfg["height"])
+        for k, val in opts:
+            ctx.set_option(k, val)
+        ctx.set_option("counters", 1)
+        ctx.upload_scene(scene)
+        ctx.render(p)
+        img, cnt = ctx.read_image(), ctx.counters()
+        ctx.close()
+        return img, cnt
+
+    ref, _ = run((("kernel", 2),))
+    monkeypatch.setenv("RTGL_DEBUG_CAND_CAP", "1000")
+    img, cnt = run((("kernel", 4), ("mf_group_quads", 2)))
+    assert cnt["candidates"] > 50_000_000
+    assert (img.view(np.uint32) == ref.view(np.uint32)).all()

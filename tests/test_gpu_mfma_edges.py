@@ -9,7 +9,7 @@ from test_gpu_parity import assert_bit_exact, run_both
 
 pytestmark = pytest.mark.gpu
 
-SCANS = [(3, 16, 2), (3, 1, 2), (4, 32, 2), (2, 1, 4), (0, 0, 1), (4, 1, 2), (3, 4, 2)]      # default and small groups of the matrix scan, fp32 scan, megakernel
+SCANS = [(4, 16, 32), (4, 1, 3), (4, 32, 32), (2, 1, 4), (0, 0, 1), (4, 1, 1), (4, 4, 5)]      # default and small groups / chunks of the matrix scan, fp32 scan, megakernel
 
 
 def scene_with(rt, vertices, spheres=True, env=32):
@@ -88,6 +88,6 @@ def test_candidate_buffer_overflow_falls_back_to_in_place_exact_tests(rt, oracle
     sc = rt.scenes
     patch = sc.grid_mesh(4, 3, x0=-12.0, x1=12.0, y0=-10.0, y1=4.0, amp=0.0).reshape(-1, 4)
     v = np.concatenate([patch] * 20 + [sc.grid_mesh(20, 10).reshape(-1, 4)])
-    r = run_both(rt, oracle, scene_with(rt, v), sc.params_c2(), 136, 72, frames=2, variant=(4, 4, 2))
+    r = run_both(rt, oracle, scene_with(rt, v), sc.params_c2(), 136, 72, frames=2, variant=(4, 4, 32))
     assert_bit_exact(r, 136, 72)
     assert r["cnt_g"]["candidates"] > 20000

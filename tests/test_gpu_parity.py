@@ -8,15 +8,15 @@ pytestmark = pytest.mark.gpu
 
 # (kernel, wf_mode, wf_rays): megakernel, wavefront with scalar-fed / LDS-tiled triangle pass
 VARIANTS = [(0, 0, 1), (1, 0, 1), (1, 0, 4), (1, 1, 2), (1, 1, 4), (2, 0, 1), (2, 0, 4), (2, 0, 8), (2, 1, 1), (2, 1, 2), (2, 1, 4), (2, 1, 8),
-            (3, 1, 2), (3, 4, 2), (3, 2, 2), (3, 16, 2), (4, 1, 2), (4, 32, 2)]   # kernel 3 = bf16 matrix-core broad phase: (3 | 4, quads per group, 32-ray sets per wave); 4 = one wave per SIMD
+            (4, 1, 3), (4, 4, 3), (4, 2, 1), (4, 16, 32), (4, 1, 32), (4, 32, 32), (4, 8, 5)]   # kernel 4 = bf16 matrix-core broad phase, one wave per SIMD: (4, quads per group, quads per chunk)
 
 
 def run_both(rt, oracle, scene, params, W, H, frames=1, rng_state=True, reset_at=None, variant=None):
     sc = rt.scenes
     ctx = rt.host.Context(W, H)
     ctx.upload_scene(scene)
-    if variant is not None and variant[0] in (3, 4):
-        ctx.set_option("kernel", variant[0]); ctx.set_option("mf_sets", variant[2]); ctx.set_option("mf_chunk_quads", 3); ctx.set_option("mf_group_quads", variant[1])
+    if variant is not None and variant[0] == 4:
+        ctx.set_option("kernel", 4); ctx.set_option("mf_chunk_quads", variant[2]); ctx.set_option("mf_group_quads", variant[1])
     elif variant is not None:
         ctx.set_option("kernel", variant[0]); ctx.set_option("wf_mode", variant[1]); ctx.set_option("wf_rays", variant[2])
         ctx.set_option("wf_chunk", 128)      # small chunks so that even the small test meshes span several work items
@@ -72,7 +72,7 @@ def test_wave_level_edge_short_circuit(rt, oracle, variant, early):
     assert_bit_exact(r, 136, 72)
 
 
-@pytest.mark.parametrize("variant", [(0, 0, 1), (1, 1, 2), (2, 1, 4), (2, 0, 8), (3, 2, 2), (4, 4, 2)])
+@pytest.mark.parametrize("variant", [(0, 0, 1), (1, 1, 2), (2, 1, 4), (2, 0, 8), (4, 2, 3), (4, 4, 32)])
 def test_two_samples_per_frame(rt, oracle, variant):
     sc = rt.scenes
     r = run_both(rt, oracle, sc.scene_mesh(20, 10, env_size=16), sc.params_c2().replace(samples=2), 64, 64, frames=2, variant=variant)
@@ -109,7 +109,7 @@ def test_triangle_free_scene_defaults_to_the_megakernel_and_explicit_choice_wins
     scene, p = sc.scene_c1(), sc.params_c1().replace(frames=1, random=sc.GlibcRand(0).rand())
     want = np.zeros((64, 64, 4), np.float32)
     oracle.render(scene, p, want, threads=4)
-    for explicit, expect in ((None, 0), (4, 4), (3, 3), (2, 2)):
+    for explicit, expect in ((None, 0), (4, 4), (1, 1), (2, 2)):
         ctx = rt.host.Context(64, 64)
         if explicit is not None:
             ctx.set_option("kernel", explicit)

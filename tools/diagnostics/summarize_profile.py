@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Turns a gpurun_out/prof_<tag>/ directory (written by scripts/gpu_profile.sh on the GPU box) into the
-tracked summaries under profiles/<tag>/ and, for the dominant kernel, profiles/hbm_traffic.json.
+"""Turns a gpurun_out/prof_<tag>/ directory (written by tools/diagnostics/gpu_profile.sh on the GPU box) into the
+tracked summaries under profiles/<tag>/ and, for the dominant kernel, an entry "<config>/<kernel>" of profiles/hbm_traffic.json.
+    python tools/diagnostics/summarize_profile.py <tag> [config]
 
 HBM traffic follows MI355X_MICROARCH.md (HBM / rocprofv3 section): FETCH_SIZE and WRITE_SIZE are
 collected in separate --pmc passes, both are in KiB, and on gfx950 FETCH_SIZE reports exactly half of
@@ -34,16 +35,20 @@ json.dump(out, open(f"{dst}/pmc_summary.json", "w"), indent=1)
 # dominant kernel (largest total time in the kernel-trace stats)
 stats = list(csv.DictReader(open(f"{dst}/kernel_stats.csv")))
 dom = max(stats, key=lambda r: float(r["TotalDurationNs"]))["Name"].split("(")[0]
-short = "intersect_mfma_kernel" if "intersect_mfma_kernel" in dom else "intersect_kernel" if "intersect_kernel" in dom else "bounce_kernel" if "bounce_kernel" in dom else "pathtrace_mega_kernel"
+short = "scan_solo_kernel" if "scan_solo_kernel" in dom else "intersect_kernel" if "intersect_kernel" in dom else "bounce_kernel" if "bounce_kernel" in dom else "pathtrace_mega_kernel"
 fetch = sum(v["FETCH_SIZE"] for k, v in out["pmc_fetch"].items() if short in k)
 fcalls = sum(v["calls"] for k, v in out["pmc_fetch"].items() if short in k)
 write = sum(v["WRITE_SIZE"] for k, v in out["pmc_write"].items() if short in k)
 wcalls = sum(v["calls"] for k, v in out["pmc_write"].items() if short in k)
 traffic = fetch * 1024 * 2 / max(fcalls, 1) + write * 1024 / max(wcalls, 1)
-json.dump({"kernel": short, "config": config, "profile": dst, "hbm_bytes_per_launch": traffic,
-           "fetch_kib_per_launch_raw": fetch / max(fcalls, 1), "write_kib_per_launch": write / max(wcalls, 1),
-           "correction": "FETCH_SIZE x2 (gfx950, wide coalesced reads), WRITE_SIZE exact; separate PMC passes"},
-          open("profiles/hbm_traffic.json", "w"), indent=1)
+path = "profiles/hbm_traffic.json"
+table = json.load(open(path)) if os.path.exists(path) else {}
+if "kernel" in table:          # round 1 wrote one unkeyed entry
+    table = {}
+table[f"{config}/{short}"] = {"profile": dst, "hbm_bytes_per_launch": traffic, "launches": fcalls,
+                              "fetch_kib_per_launch_raw": fetch / max(fcalls, 1), "write_kib_per_launch": write / max(wcalls, 1),
+                              "correction": "FETCH_SIZE x2 (gfx950, wide coalesced reads), WRITE_SIZE exact; separate PMC passes"}
+json.dump(table, open(path, "w"), indent=1)
 print(open("profiles/hbm_traffic.json").read())
 for r in stats[:6]:
     print(r["Name"][:70], r["Calls"], "avg_us", float(r["AverageNs"]) / 1e3)
