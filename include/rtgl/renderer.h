@@ -139,8 +139,23 @@ public:
     Renderer(int width, int height, int device = 0, int rank = 0, int world = 1, int strip_rows = 16)
         : Window(width, height, "Pathtracer"), m_camera(glm::vec3(0.0f, 0.0f, -35.0f), 33.0f)
     {
-        if (rtgl_create_tiled(&m_ctx, width, height, device, rank, world, strip_rows) != RTGL_OK) {
+        std::vector<int> devices;                                               // RTGL_AMD_DEVICES=0,1,2,3: tile the frame across these GPUs
+        if (const char *env = std::getenv("RTGL_AMD_DEVICES"))
+            for (const char *c = env; *c;) { char *end = nullptr; const long v = std::strtol(c, &end, 10); if (end == c) break; devices.push_back((int)v); c = (*end == ',') ? end + 1 : end; }
+        const int rc = (world == 1 && devices.size() > 1) ? rtgl_create_multi(&m_ctx, width, height, devices.data(), (int)devices.size(), 8)
+                                                          : rtgl_create_tiled(&m_ctx, width, height, device, rank, world, strip_rows);
+        if (rc != RTGL_OK) {
             std::cerr << "rtgl: " << rtgl_last_error(nullptr) << std::endl;     // the reference prints and carries on
+            m_ctx = nullptr;
+        }
+    }
+    // one process, several devices: the frame is tiled across `devices` (strips of strip_rows rows) and gathered to devices[0]
+    // when it is read or saved; RTGL_AMD_DEVICES=0,1,2,... does the same for an unmodified caller of Renderer(width, height)
+    Renderer(int width, int height, const std::vector<int> &devices, int strip_rows = 8)
+        : Window(width, height, "Pathtracer"), m_camera(glm::vec3(0.0f, 0.0f, -35.0f), 33.0f)
+    {
+        if (rtgl_create_multi(&m_ctx, width, height, devices.data(), (int)devices.size(), strip_rows) != RTGL_OK) {
+            std::cerr << "rtgl: " << rtgl_last_error(nullptr) << std::endl;
             m_ctx = nullptr;
         }
     }

@@ -91,6 +91,17 @@ int rtgl_create(rtgl_context **out, int width, int height, int device);
  * must be a multiple of 8.  (No reference counterpart: SURVEY.md 8(e).) */
 int rtgl_create_tiled(rtgl_context **out, int width, int height, int device, int rank, int world, int strip_rows);
 
+/* Single-process multi-device context: the image is cut into strips of strip_rows rows, strip s belongs to
+ * devices[s % n_devices]; every device holds the whole scene and renders its strips (one dispatch per device replaces the single
+ * glDispatchCompute of src/renderer.cpp:129-134); the tile buffers are gathered to devices[0] (peer copies over xGMI, one 2-D copy
+ * per device) when the image is read -- rtgl_read_image_* do it implicitly, rtgl_gather_tiles explicitly (then rtgl_device_image
+ * is the assembled image on devices[0]).  Every other entry point takes the handle like a single-device one: uploads and options
+ * go to all devices, counters are summed, rtgl_last_frame_ms is the slowest device.  Bit-identical to a single-device render.
+ * The same ordinal may appear more than once.  rtgl_bind_device_image / rtgl_set_stream are refused on such a handle. */
+int rtgl_create_multi(rtgl_context **out, int width, int height, const int *devices, int n_devices, int strip_rows);
+int rtgl_device_count(const rtgl_context *ctx);   /* 1 for a single-device context */
+int rtgl_gather_tiles(rtgl_context *ctx);         /* enqueue the gather on devices[0]'s stream (no-op for a single-device context) */
+
 void rtgl_destroy(rtgl_context *ctx);
 const char *rtgl_last_error(const rtgl_context *ctx); /* ctx may be NULL: error of the last failed create */
 

@@ -338,6 +338,7 @@ scan_solo_kernel(SceneView sc, WaveBuffers wb, MfView mf, uint32_t bounce, uint3
     }
 #endif
     if (lane == 0) wb.cand_counts[region] = (uint32_t)(appended < (unsigned long long)wb.cand_region ? appended : (unsigned long long)wb.cand_region);
+    if (lane == 0 && appended > (unsigned long long)*wb.cand_peak) atomicMax(wb.cand_peak, (uint32_t)(appended < 0xFFFFFFF0ull ? appended : 0xFFFFFFF0ull));   // (racy pre-check: only saves atomics)
     if (kCount) {
         atomicAdd(&counters->candidates, c_cand_total);
         if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&counters->tri_tests, (unsigned long long)n_rays * (v_chunk_end - v_chunk_begin));

@@ -185,12 +185,22 @@ struct rtgl_context {
     hipEvent_t counts_ev = nullptr; bool counts_pending = false, counts_valid = false;
     bool timing_this_frame = false; uint32_t timing_frame_counter = 0;
     int kernel_in_use = -1;                  // variant the last frame actually ran
-    bool wave_has_cand = false; int n_cus = 256; uint32_t cand_regions = 0;
+    int n_cus = 256;
+    // kernel 4 candidate buffer: one region per wave of a scan launch.  Sized from what the scene needs, not from the image: it starts
+    // at 1.5 pairs per ray and grows to 1.25 x the fullest region any finished frame reported (pairs that do not fit are tested
+    // in place by the scan, so every size is correct; a too small one is only slower)
+    uint2 *d_cand = nullptr; uint32_t cand_regions = 0, cand_region_pairs = 0, cand_region_target = 0; bool cand_fixed = false;
     bool solo_attr_set = false;              // hipFuncAttributeMaxDynamicSharedMemorySize is per device: raised once per context (= per device binding)
     bool kernel_explicit = false;            // "kernel" was set through rtgl_set_option or RTGL_AMD_KERNEL
     uint32_t counts_n0 = 0, counts_len = 0;
     std::vector<uint32_t> est_counts;        // grid-size estimates for the next frame
     WaveBuffers wb{};
+
+    // single-process multi-device mode (rtgl_create_multi): this context is the assembler -- it owns the full image on devices[0] --
+    // and `parts` are the per-device tiled contexts that render the strips; every entry point fans out to them
+    std::vector<rtgl_context *> parts;
+    std::vector<hipEvent_t> part_done;
+    bool gathered = false, peer_copy = true;
 
     bool tris_dirty = false, visits_dirty = false;
     FrameParams params{};
@@ -269,7 +279,10 @@ extern "C" int rtgl_create(rtgl_context **out, int width, int height, int device
 extern "C" void rtgl_destroy(rtgl_context *ctx)
 {
     if (!ctx) return;
+    for (rtgl_context *part : ctx->parts) rtgl_destroy(part);
+    ctx->parts.clear();
     (void)hipSetDevice(ctx->device);
+    for (hipEvent_t e : ctx->part_done) (void)hipEventDestroy(e);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
 #ifdef RT_SOLO_STAMPS
     if (ctx->d_dbg_log) {      // diagnostics build: where the waves of the solo scan spent their cycles, per bounce, summed over all frames
@@ -285,7 +298,7 @@ extern "C" void rtgl_destroy(rtgl_context *ctx)
 #endif
     void *ptrs[] = { ctx->d_spheres, ctx->d_materials, ctx->d_vertices, ctx->d_sphere_visits, ctx->d_edges, ctx->d_planes,
                      ctx->d_env, ctx->d_image_own, ctx->d_rng, ctx->d_counters, ctx->d_u8, ctx->d_group_bounds, ctx->d_wave, ctx->d_counts, ctx->d_mf_groups, ctx->d_mf_A, ctx->d_mf_order,
-                     ctx->d_dbg_log };
+                     ctx->d_dbg_log, ctx->d_cand };
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (hipEvent_t e : ctx->kev) (void)hipEventDestroy(e);
     if (ctx->h_counts) (void)hipHostFree(ctx->h_counts);
@@ -299,10 +312,91 @@ extern "C" void rtgl_destroy(rtgl_context *ctx)
 extern "C" const char *rtgl_last_error(const rtgl_context *ctx) { return ctx ? ctx->error.c_str() : g_create_error.c_str(); }
 
 #define ENTER(ctx) do { if (!(ctx)) return RTGL_ERR_INVALID; HIPCHK(ctx, hipSetDevice((ctx)->device)); } while (0)
+// multi-device context: run `call` on every part, report the first failure through the assembler
+#define FANOUT(ctx, call) do { if (!(ctx)->parts.empty()) { (ctx)->gathered = false; \
+    for (rtgl_context *part : (ctx)->parts) { const int rc_ = (call); if (rc_) return fail(ctx, rc_, std::string("device ") + std::to_string(part->device) + ": " + part->error); } \
+    return RTGL_OK; } } while (0)
+
+// ---- single-process multi-device context (create(w, h, devices[], n)) --------------------------------------------
+// Replaces the ONE glDispatchCompute of the reference (src/renderer.cpp:129-134) by one strip-tiled dispatch per device; the tile
+// buffers are gathered to devices[0] over xGMI (peer copies, one 2-D copy per part: strips of a part are `world` strips apart in
+// the assembled image) when the image is consumed.  The same device may be listed more than once (several contexts on one GPU).
+extern "C" int rtgl_create_multi(rtgl_context **out, int width, int height, const int *devices, int n_devices, int strip_rows)
+{
+    if (!out) return fail(nullptr, RTGL_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    if (!devices || n_devices < 1 || n_devices > 64) return fail(nullptr, RTGL_ERR_INVALID, "rtgl_create_multi: need 1..64 device ordinals");
+    rtgl_context *ctx = nullptr;
+    int rc = rtgl_create_tiled(&ctx, width, height, devices[0], 0, 1, strip_rows);         // the assembler: full image on devices[0]
+    if (rc) return rc;
+    for (int i = 0; i < n_devices; ++i) {
+        rtgl_context *part = nullptr;
+        rc = rtgl_create_tiled(&part, width, height, devices[i], i, n_devices, strip_rows);
+        if (rc) { const std::string msg = g_create_error; rtgl_destroy(ctx); g_create_error = msg; return rc; }
+        ctx->parts.push_back(part);
+        hipEvent_t ev = nullptr;
+        (void)hipSetDevice(devices[i]);
+        if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { rtgl_destroy(ctx); return fail(nullptr, RTGL_ERR_DEVICE, "hipEventCreate failed"); }
+        ctx->part_done.push_back(ev);
+        if (devices[i] != devices[0]) {           // xGMI peer copies; without peer access the gather goes through the host
+            int can = 0;
+            (void)hipSetDevice(devices[0]);
+            if (hipDeviceCanAccessPeer(&can, devices[0], devices[i]) != hipSuccess || !can) ctx->peer_copy = false;
+            else { hipError_t e = hipDeviceEnablePeerAccess(devices[i], 0); if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) ctx->peer_copy = false; }
+            (void)hipGetLastError();
+        }
+    }
+    *out = ctx;
+    return RTGL_OK;
+}
+
+extern "C" int rtgl_device_count(const rtgl_context *ctx) { return ctx ? (ctx->parts.empty() ? 1 : (int)ctx->parts.size()) : RTGL_ERR_INVALID; }
+
+// strips of every part -> the assembler's image (global row order), on the assembler's stream, after each part's queued frames
+static int multi_gather(rtgl_context *ctx)
+{
+    if (ctx->gathered) return RTGL_OK;
+    const int world = (int)ctx->parts.size(), sr = ctx->strip_rows;
+    const size_t row_bytes = (size_t)ctx->width * 16, strip_bytes = row_bytes * sr;
+    std::vector<float> host;
+    for (int i = 0; i < world; ++i) {
+        rtgl_context *part = ctx->parts[i];
+        const int full = part->local_rows / sr, tail_rows = part->local_rows - full * sr;       // only the owner of the last strip has a short one
+        uint8_t *dst = reinterpret_cast<uint8_t *>(ctx->d_image) + (size_t)i * strip_bytes;
+        const uint8_t *src = reinterpret_cast<const uint8_t *>(part->d_image);
+        if (ctx->peer_copy) {
+            HIPCHK(ctx, hipSetDevice(part->device));
+            HIPCHK(ctx, hipEventRecord(ctx->part_done[i], part->stream));
+            HIPCHK(ctx, hipSetDevice(ctx->device));
+            HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->part_done[i], 0));
+            if (full) HIPCHK(ctx, hipMemcpy2DAsync(dst, (size_t)world * strip_bytes, src, strip_bytes, strip_bytes, (size_t)full, hipMemcpyDeviceToDevice, ctx->stream));
+            if (tail_rows) HIPCHK(ctx, hipMemcpyAsync(dst + (size_t)full * world * strip_bytes, src + (size_t)full * strip_bytes, row_bytes * tail_rows, hipMemcpyDeviceToDevice, ctx->stream));
+        } else {
+            host.resize((size_t)part->local_rows * ctx->width * 4);
+            int rc = rtgl_read_image_f32(part, host.data());
+            if (rc) return fail(ctx, rc, part->error);
+            HIPCHK(ctx, hipSetDevice(ctx->device));
+            if (full) HIPCHK(ctx, hipMemcpy2DAsync(dst, (size_t)world * strip_bytes, host.data(), strip_bytes, strip_bytes, (size_t)full, hipMemcpyHostToDevice, ctx->stream));
+            if (tail_rows) HIPCHK(ctx, hipMemcpyAsync(dst + (size_t)full * world * strip_bytes, reinterpret_cast<const uint8_t *>(host.data()) + (size_t)full * strip_bytes, row_bytes * tail_rows, hipMemcpyHostToDevice, ctx->stream));
+            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        }
+    }
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    ctx->gathered = true;
+    return RTGL_OK;
+}
+
+extern "C" int rtgl_gather_tiles(rtgl_context *ctx)
+{
+    ENTER(ctx);
+    if (ctx->parts.empty()) return RTGL_OK;            // a single-device context holds its image already
+    return multi_gather(ctx);
+}
 
 extern "C" int rtgl_upload_spheres(rtgl_context *ctx, const void *data, uint32_t count)
 {
     ENTER(ctx);
+    FANOUT(ctx, rtgl_upload_spheres(part, data, count));
     if (count && !data) return fail(ctx, RTGL_ERR_INVALID, "spheres is NULL");
     static_assert(sizeof(SphereRec) == 32, "Sphere stride (shaders/raytracer.glsl:11-15, std140)");
     int rc = realloc_upload(ctx, ctx->d_spheres, data, (size_t)count * 32);
@@ -314,6 +408,7 @@ extern "C" int rtgl_upload_spheres(rtgl_context *ctx, const void *data, uint32_t
 extern "C" int rtgl_upload_materials(rtgl_context *ctx, const void *data, uint32_t count)
 {
     ENTER(ctx);
+    FANOUT(ctx, rtgl_upload_materials(part, data, count));
     if (count && !data) return fail(ctx, RTGL_ERR_INVALID, "materials is NULL");
     static_assert(sizeof(MaterialRec) == 32, "Material stride (shaders/raytracer.glsl:17-21, std140)");
     int rc = realloc_upload(ctx, ctx->d_materials, data, (size_t)count * 32);
@@ -325,6 +420,7 @@ extern "C" int rtgl_upload_materials(rtgl_context *ctx, const void *data, uint32
 extern "C" int rtgl_upload_meshes(rtgl_context *ctx, const void *data, uint32_t count)
 {
     ENTER(ctx);
+    FANOUT(ctx, rtgl_upload_meshes(part, data, count));
     if (count && !data) return fail(ctx, RTGL_ERR_INVALID, "meshes is NULL");
     ctx->h_meshes.assign((const uint8_t *)data, (const uint8_t *)data + (size_t)count * 16);
     ctx->n_meshes = count; ctx->tris_dirty = true;
@@ -334,6 +430,7 @@ extern "C" int rtgl_upload_meshes(rtgl_context *ctx, const void *data, uint32_t 
 extern "C" int rtgl_upload_vertices(rtgl_context *ctx, const void *data, uint32_t vec4_count)
 {
     ENTER(ctx);
+    FANOUT(ctx, rtgl_upload_vertices(part, data, vec4_count));
     if (vec4_count && !data) return fail(ctx, RTGL_ERR_INVALID, "vertices is NULL");
     int rc = realloc_upload(ctx, ctx->d_vertices, data, (size_t)vec4_count * 16);
     if (rc) return rc;
@@ -345,6 +442,7 @@ extern "C" int rtgl_upload_vertices(rtgl_context *ctx, const void *data, uint32_
 extern "C" int rtgl_upload_nodes(rtgl_context *ctx, const void *data, uint32_t count)
 {
     ENTER(ctx);
+    FANOUT(ctx, rtgl_upload_nodes(part, data, count));
     if (count && !data) return fail(ctx, RTGL_ERR_INVALID, "nodes is NULL");
     ctx->h_nodes.assign((const uint8_t *)data, (const uint8_t *)data + (size_t)count * 48);
     ctx->n_nodes = count; ctx->visits_dirty = true;
@@ -354,6 +452,7 @@ extern "C" int rtgl_upload_nodes(rtgl_context *ctx, const void *data, uint32_t c
 extern "C" int rtgl_upload_envmap(rtgl_context *ctx, const uint8_t *faces, int nfaces, int width, int height, int channels)
 {
     ENTER(ctx);
+    FANOUT(ctx, rtgl_upload_envmap(part, faces, nfaces, width, height, channels));
     if (nfaces < 0 || nfaces > 6 || width <= 0 || height <= 0 || (channels != 3 && channels != 4) || (nfaces && !faces))
         return fail(ctx, RTGL_ERR_INVALID, "envmap: need 0..6 faces, positive size, 3 or 4 channels");
     int rc = realloc_upload(ctx, ctx->d_env, faces, (size_t)nfaces * width * height * channels);
@@ -502,7 +601,7 @@ static void kev_mark(rtgl_context *ctx)
 static uint32_t solo_chunks(const rtgl_context *ctx);
 static uint32_t solo_regions(const rtgl_context *ctx) { return std::max<uint32_t>((uint32_t)ctx->n_cus, solo_chunks(ctx)) * 4u; }
 
-static size_t counts_bytes(uint32_t capacity) { return (size_t)capacity * sizeof(uint32_t); }
+static size_t counts_bytes(uint32_t capacity) { return (size_t)(capacity + 1u) * sizeof(uint32_t); }      // ray counts per bounce + the fullest candidate region
 
 static int ensure_wave_buffers(rtgl_context *ctx, uint32_t n0, uint32_t max_bounce, bool multi_sample)
 {
@@ -510,22 +609,31 @@ static int ensure_wave_buffers(rtgl_context *ctx, uint32_t n0, uint32_t max_boun
         if (ctx->d_counts) { HIPCHK(ctx, hipFree(ctx->d_counts)); ctx->d_counts = nullptr; }
         HIPCHK(ctx, hipMalloc((void **)&ctx->d_counts, counts_bytes(max_bounce + 2)));                          // u32 ray counts per bounce
         if (ctx->h_counts) { HIPCHK(ctx, hipHostFree(ctx->h_counts)); ctx->h_counts = nullptr; }
-        HIPCHK(ctx, hipHostMalloc((void **)&ctx->h_counts, (size_t)(max_bounce + 2) * sizeof(uint32_t), hipHostMallocDefault));
+        HIPCHK(ctx, hipHostMalloc((void **)&ctx->h_counts, counts_bytes(max_bounce + 2), hipHostMallocDefault));
         if (!ctx->counts_ev) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->counts_ev, hipEventDisableTiming));
         ctx->counts_capacity = max_bounce + 2; ctx->counts_pending = ctx->counts_valid = false; ctx->est_counts.clear();
     }
     const size_t local_px = (size_t)std::max(ctx->local_rows, 1) * ctx->width;
-    const bool want_cand = ctx->opt_kernel == RTGL_KERNEL_WAVEFRONT_MFMA_SOLO;
-    const uint32_t need_regions = want_cand ? solo_regions(ctx) : 0u;
-    if (ctx->wave_capacity < n0 || (multi_sample && !ctx->wave_multi) || (want_cand && !ctx->wave_has_cand) || need_regions > ctx->cand_regions) {
+    if (ctx->opt_kernel == RTGL_KERNEL_WAVEFRONT_MFMA_SOLO) {
+        const uint32_t need_regions = solo_regions(ctx);
+        if (!ctx->cand_region_target) ctx->cand_region_target = std::max<uint32_t>(4096u, (uint32_t)std::min<uint64_t>(((uint64_t)n0 * 3 / 2 + need_regions - 1) / need_regions, 0xFFFFFFF0u));
+        if (!ctx->d_cand || need_regions > ctx->cand_regions || ctx->cand_region_target > ctx->cand_region_pairs) {
+            if (ctx->d_cand) { HIPCHK(ctx, hipFree(ctx->d_cand)); ctx->d_cand = nullptr; }                  // (hipFree waits for the frames in flight)
+            ctx->cand_regions = need_regions; ctx->cand_region_pairs = ctx->cand_region_target;
+            HIPCHK(ctx, hipMalloc((void **)&ctx->d_cand, ((size_t)need_regions * ctx->cand_region_pairs) * sizeof(uint2) + (size_t)need_regions * sizeof(uint32_t) + 256));
+        }
+        ctx->wb.cand = ctx->d_cand;
+        ctx->wb.cand_counts = reinterpret_cast<uint32_t *>(ctx->d_cand + (size_t)ctx->cand_regions * ctx->cand_region_pairs);
+        ctx->wb.cand_region = ctx->cand_region_pairs;
+        // diagnostics: RTGL_DEBUG_CAND_CAP=n pretends a wave's region holds n pairs only, so that the in-place fallback of the scan runs
+        if (const char *cc = getenv("RTGL_DEBUG_CAND_CAP")) { ctx->wb.cand_region = std::min<uint32_t>(ctx->wb.cand_region, (uint32_t)atoi(cc)); ctx->cand_fixed = true; }
+    }
+    if (ctx->wave_capacity < n0 || (multi_sample && !ctx->wave_multi)) {
         if (ctx->d_wave) { HIPCHK(ctx, hipFree(ctx->d_wave)); ctx->d_wave = nullptr; }
         // per queue: 4 x 16 B + 4 B per ray; per-pixel state for u_samples > 1: 4 x 16 B
-        const size_t cand_cap = ctx->opt_kernel == RTGL_KERNEL_WAVEFRONT_MFMA_SOLO ? std::max<size_t>((size_t)n0 * 32, (size_t)1 << 20) : 0;   // pairs of one bounce (8 B each; overflow is tested in place)
-        const size_t n_regions = std::max<size_t>(need_regions, 4);                                                // one per wave of a scan launch
-        ctx->cand_regions = (uint32_t)n_regions;
-        size_t q_bytes = (size_t)n0 * (68 + 8), bytes = 2 * q_bytes + 1024 + cand_cap * 8 + n_regions * 4 + 256 + (multi_sample ? local_px * 64 : 0);
+        size_t q_bytes = (size_t)n0 * (68 + 8), bytes = 2 * q_bytes + 1024 + (multi_sample ? local_px * 64 : 0);
         HIPCHK(ctx, hipMalloc(&ctx->d_wave, bytes));
-        ctx->wave_capacity = n0; ctx->wave_multi = multi_sample; ctx->wave_has_cand = want_cand;
+        ctx->wave_capacity = n0; ctx->wave_multi = multi_sample;
         uint8_t *p = (uint8_t *)ctx->d_wave;
         for (int q = 0; q < 2; ++q) {
             ctx->wb.q[q].a = (float4 *)p; p += (size_t)n0 * 16;
@@ -536,12 +644,6 @@ static int ensure_wave_buffers(rtgl_context *ctx, uint32_t n0, uint32_t max_boun
         for (int q = 0; q < 2; ++q) { ctx->wb.best[q] = (unsigned long long *)p; p += (size_t)n0 * 8; }
         for (int q = 0; q < 2; ++q) { ctx->wb.q[q].pixel = (uint32_t *)p; p += (size_t)n0 * 4; }
         p = (uint8_t *)(((uintptr_t)p + 255) & ~(uintptr_t)255);
-        ctx->wb.cand = (uint2 *)p; p += cand_cap * 8; ctx->wb.cand_region = (uint32_t)std::min<size_t>(cand_cap / n_regions, 0xFFFFFFF0u);
-        // diagnostics: RTGL_DEBUG_CAND_CAP=n pretends a wave's region holds n pairs only, so that the in-place fallback of the scan runs
-        if (const char *cc = getenv("RTGL_DEBUG_CAND_CAP")) ctx->wb.cand_region = std::min<uint32_t>(ctx->wb.cand_region, (uint32_t)atoi(cc));
-        p = (uint8_t *)(((uintptr_t)p + 255) & ~(uintptr_t)255);
-        ctx->wb.cand_counts = (uint32_t *)p; p += n_regions * 4;
-        p = (uint8_t *)(((uintptr_t)p + 255) & ~(uintptr_t)255);
         if (multi_sample) {
             ctx->wb.sums = (float4 *)p; p += local_px * 16;
             ctx->wb.cam_a = (float4 *)p; p += local_px * 16;
@@ -550,6 +652,7 @@ static int ensure_wave_buffers(rtgl_context *ctx, uint32_t n0, uint32_t max_boun
         } else ctx->wb.sums = ctx->wb.cam_a = ctx->wb.cam_b = nullptr, ctx->wb.pix_rng = nullptr;
     }
     ctx->wb.counts = ctx->d_counts;
+    ctx->wb.cand_peak = ctx->d_counts + ctx->counts_capacity;
     ctx->wb.group_bounds = ctx->d_group_bounds;
     return RTGL_OK;
 }
@@ -640,6 +743,9 @@ static int launch_wavefront(rtgl_context *ctx, const SceneView &sc, const FrameP
         ctx->counts_pending = false;
         if (ctx->counts_n0 == n0) ctx->est_counts.assign(ctx->h_counts, ctx->h_counts + ctx->counts_len);
         else ctx->est_counts.clear();
+        // the fullest candidate region of that frame: grow before the NEXT frame is enqueued (ensure_wave_buffers), never shrink
+        const uint32_t peak = ctx->h_counts[ctx->counts_capacity];
+        if (!ctx->cand_fixed && peak > ctx->cand_region_pairs) ctx->cand_region_target = (uint32_t)std::min<uint64_t>((uint64_t)peak + peak / 4, 0xFFFFFFF0u);
     }
     for (uint32_t s = 0; s < P.samples; ++s) {
         HIPCHK(ctx, hipMemsetAsync(ctx->d_counts, 0, counts_bytes(ctx->counts_capacity), ctx->stream));
@@ -694,7 +800,7 @@ static int launch_wavefront(rtgl_context *ctx, const SceneView &sc, const FrameP
     }
     if (!ctx->counts_pending) {      // feed the next frames' grid sizes; skipped while an earlier copy is in flight
         ctx->counts_len = P.max_bounce + 1; ctx->counts_n0 = n0;
-        HIPCHK(ctx, hipMemcpyAsync(ctx->h_counts, ctx->d_counts, (size_t)ctx->counts_len * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(ctx->h_counts, ctx->d_counts, counts_bytes(ctx->counts_capacity), hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(ctx, hipEventRecord(ctx->counts_ev, ctx->stream));
         ctx->counts_pending = true;
     }
@@ -704,6 +810,7 @@ static int launch_wavefront(rtgl_context *ctx, const SceneView &sc, const FrameP
 extern "C" int rtgl_set_frame_params(rtgl_context *ctx, const rtgl_frame_params *p)
 {
     ENTER(ctx);
+    FANOUT(ctx, rtgl_set_frame_params(part, p));
     if (!p) return fail(ctx, RTGL_ERR_INVALID, "params is NULL");
     static_assert(sizeof(FrameParams) == sizeof(rtgl_frame_params), "FrameParams mirrors rtgl_frame_params");
     memcpy(&ctx->params, p, sizeof(FrameParams));
@@ -714,6 +821,7 @@ extern "C" int rtgl_set_frame_params(rtgl_context *ctx, const rtgl_frame_params 
 extern "C" int rtgl_render_frame(rtgl_context *ctx)
 {
     ENTER(ctx);
+    FANOUT(ctx, rtgl_render_frame(part));
     if (!ctx->have_params) return fail(ctx, RTGL_ERR_STATE, "rtgl_set_frame_params has not been called");
     if (ctx->params.samples == 0) return fail(ctx, RTGL_ERR_INVALID, "u_samples == 0 divides by zero in the reference; refused");
     if (ctx->visits_dirty) { int rc = rebuild_sphere_visits(ctx); if (rc) return rc; }
@@ -776,6 +884,8 @@ extern "C" int rtgl_render_frame(rtgl_context *ctx)
 extern "C" int rtgl_synchronize(rtgl_context *ctx)
 {
     ENTER(ctx);
+    for (rtgl_context *part : ctx->parts) { const int rc = rtgl_synchronize(part); if (rc) return fail(ctx, rc, part->error); }
+    HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return RTGL_OK;
 }
@@ -783,6 +893,12 @@ extern "C" int rtgl_synchronize(rtgl_context *ctx)
 extern "C" int rtgl_last_frame_ms(rtgl_context *ctx, float *ms)
 {
     ENTER(ctx);
+    if (!ctx->parts.empty()) {
+        if (!ms) return fail(ctx, RTGL_ERR_INVALID, "ms is NULL");
+        *ms = 0.0f;
+        for (rtgl_context *part : ctx->parts) { float m = 0.0f; const int rc = rtgl_last_frame_ms(part, &m); if (rc) return fail(ctx, rc, part->error); *ms = std::max(*ms, m); }
+        return RTGL_OK;
+    }
     if (!ms || !ctx->timed) return fail(ctx, RTGL_ERR_STATE, "no frame has been rendered");
     HIPCHK(ctx, hipEventSynchronize(ctx->ev1));
     HIPCHK(ctx, hipEventElapsedTime(ms, ctx->ev0, ctx->ev1));
@@ -810,6 +926,7 @@ static int sum_timing(rtgl_context *ctx, size_t first, size_t last, rtgl_frame_t
 extern "C" int rtgl_last_frame_timing(rtgl_context *ctx, rtgl_frame_timing *out)
 {
     ENTER(ctx);
+    if (!ctx->parts.empty()) { const int rc = rtgl_last_frame_timing(ctx->parts[0], out); return rc ? fail(ctx, rc, ctx->parts[0]->error) : RTGL_OK; }   // device 0's share
     if (!out || !ctx->timed) return fail(ctx, RTGL_ERR_STATE, "no frame has been rendered");
     if (!ctx->opt_kernel_timing || ctx->kev_frame_start.empty()) return fail(ctx, RTGL_ERR_STATE, "option kernel_timing was not enabled before rendering");
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -819,6 +936,7 @@ extern "C" int rtgl_last_frame_timing(rtgl_context *ctx, rtgl_frame_timing *out)
 extern "C" int rtgl_accumulated_timing(rtgl_context *ctx, rtgl_frame_timing *out, uint32_t *frames_out)
 {
     ENTER(ctx);
+    if (!ctx->parts.empty()) { const int rc = rtgl_accumulated_timing(ctx->parts[0], out, frames_out); return rc ? fail(ctx, rc, ctx->parts[0]->error) : RTGL_OK; }
     if (!out) return fail(ctx, RTGL_ERR_INVALID, "out is NULL");
     if (!ctx->opt_kernel_timing) return fail(ctx, RTGL_ERR_STATE, "option kernel_timing is not enabled");
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -829,6 +947,7 @@ extern "C" int rtgl_accumulated_timing(rtgl_context *ctx, rtgl_frame_timing *out
 extern "C" int rtgl_timing_reset(rtgl_context *ctx)
 {
     ENTER(ctx);
+    FANOUT(ctx, rtgl_timing_reset(part));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     ctx->kev_used = 0; ctx->kev_frame_start.clear(); ctx->timing_frame_counter = 0;
     return RTGL_OK;
@@ -838,6 +957,7 @@ extern "C" int rtgl_read_image_f32(rtgl_context *ctx, float *rgba)
 {
     ENTER(ctx);
     if (!rgba) return fail(ctx, RTGL_ERR_INVALID, "rgba is NULL");
+    if (!ctx->parts.empty()) { const int rc = multi_gather(ctx); if (rc) return rc; }
     HIPCHK(ctx, hipMemcpyAsync(rgba, ctx->d_image, (size_t)ctx->local_rows * ctx->width * 16, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return RTGL_OK;
@@ -847,6 +967,18 @@ extern "C" int rtgl_write_image_f32(rtgl_context *ctx, const float *rgba)
 {
     ENTER(ctx);
     if (!rgba) return fail(ctx, RTGL_ERR_INVALID, "rgba is NULL");
+    if (!ctx->parts.empty()) {                          // scatter the rows to their owners
+        ctx->gathered = false;
+        std::vector<float> local;
+        for (rtgl_context *part : ctx->parts) {
+            local.resize((size_t)std::max(part->local_rows, 1) * ctx->width * 4);
+            for (int lr = 0; lr < part->local_rows; ++lr)
+                memcpy(local.data() + (size_t)lr * ctx->width * 4, rgba + (size_t)rtgl_local_row_to_global(part, lr) * ctx->width * 4, (size_t)ctx->width * 16);
+            const int rc = rtgl_write_image_f32(part, local.data());
+            if (rc) return fail(ctx, rc, part->error);
+        }
+        return RTGL_OK;
+    }
     HIPCHK(ctx, hipMemcpyAsync(ctx->d_image, rgba, (size_t)ctx->local_rows * ctx->width * 16, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return RTGL_OK;
@@ -855,6 +987,7 @@ extern "C" int rtgl_write_image_f32(rtgl_context *ctx, const float *rgba)
 extern "C" int rtgl_clear_image(rtgl_context *ctx)
 {
     ENTER(ctx);
+    FANOUT(ctx, rtgl_clear_image(part));
     HIPCHK(ctx, hipMemsetAsync(ctx->d_image, 0, (size_t)ctx->local_rows * ctx->width * 16, ctx->stream));
     return RTGL_OK;
 }
@@ -863,6 +996,7 @@ extern "C" int rtgl_read_image_u8(rtgl_context *ctx, uint8_t *rgba, int flip)
 {
     ENTER(ctx);
     if (!rgba) return fail(ctx, RTGL_ERR_INVALID, "rgba is NULL");
+    if (!ctx->parts.empty()) { const int rc = multi_gather(ctx); if (rc) return rc; }
     size_t n = (size_t)ctx->local_rows * ctx->width;
     if (n == 0) return RTGL_OK;
     if (!ctx->d_u8) HIPCHK(ctx, hipMalloc((void **)&ctx->d_u8, n * 4));
@@ -889,6 +1023,7 @@ extern "C" void *rtgl_device_image(rtgl_context *ctx) { return ctx ? (void *)ctx
 extern "C" int rtgl_bind_device_image(rtgl_context *ctx, void *dptr)
 {
     ENTER(ctx);
+    if (!ctx->parts.empty()) return fail(ctx, RTGL_ERR_STATE, "a multi-device context renders into its own per-device tile buffers");
     ctx->d_image = dptr ? (float4 *)dptr : ctx->d_image_own;
     return RTGL_OK;
 }
@@ -896,6 +1031,7 @@ extern "C" int rtgl_bind_device_image(rtgl_context *ctx, void *dptr)
 extern "C" int rtgl_set_stream(rtgl_context *ctx, void *hip_stream)
 {
     ENTER(ctx);
+    if (!ctx->parts.empty()) return fail(ctx, RTGL_ERR_STATE, "a multi-device context owns one stream per device");
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
     return RTGL_OK;
@@ -905,6 +1041,15 @@ extern "C" int rtgl_get_counters(rtgl_context *ctx, rtgl_counters *out)
 {
     ENTER(ctx);
     if (!out) return fail(ctx, RTGL_ERR_INVALID, "out is NULL");
+    if (!ctx->parts.empty()) {
+        memset(out, 0, sizeof *out);
+        for (rtgl_context *part : ctx->parts) {
+            rtgl_counters c; const int rc = rtgl_get_counters(part, &c);
+            if (rc) return fail(ctx, rc, part->error);
+            out->paths += c.paths; out->segments += c.segments; out->triangle_tests += c.triangle_tests; out->candidates += c.candidates; out->env_lookups += c.env_lookups;
+        }
+        return RTGL_OK;
+    }
     Counters c;
     HIPCHK(ctx, hipMemcpyAsync(&c, ctx->d_counters, sizeof c, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -918,6 +1063,17 @@ extern "C" int rtgl_read_rng_state(rtgl_context *ctx, uint32_t *xyzw)
 {
     ENTER(ctx);
     if (!xyzw) return fail(ctx, RTGL_ERR_INVALID, "xyzw is NULL");
+    if (!ctx->parts.empty()) {                          // rows from their owners, global row order
+        std::vector<uint32_t> local;
+        for (rtgl_context *part : ctx->parts) {
+            local.resize((size_t)std::max(part->local_rows, 1) * ctx->width * 4);
+            const int rc = rtgl_read_rng_state(part, local.data());
+            if (rc) return fail(ctx, rc, part->error);
+            for (int lr = 0; lr < part->local_rows; ++lr)
+                memcpy(xyzw + (size_t)rtgl_local_row_to_global(part, lr) * ctx->width * 4, local.data() + (size_t)lr * ctx->width * 4, (size_t)ctx->width * 16);
+        }
+        return RTGL_OK;
+    }
     if (!ctx->opt_rng_state || !ctx->d_rng) return fail(ctx, RTGL_ERR_STATE, "option rng_state was not enabled before rendering");
     HIPCHK(ctx, hipMemcpyAsync(xyzw, ctx->d_rng, (size_t)ctx->local_rows * ctx->width * 16, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -927,6 +1083,7 @@ extern "C" int rtgl_read_rng_state(rtgl_context *ctx, uint32_t *xyzw)
 extern "C" int rtgl_set_option(rtgl_context *ctx, const char *key, int value)
 {
     ENTER(ctx);
+    FANOUT(ctx, rtgl_set_option(part, key, value));
     if (!key) return fail(ctx, RTGL_ERR_INVALID, "key is NULL");
     if (!strcmp(key, "kernel")) {
         if (value == RTGL_KERNEL_REMOVED_3)
@@ -972,6 +1129,7 @@ extern "C" int rtgl_get_option(rtgl_context *ctx, const char *key, int *value)
 {
     ENTER(ctx);
     if (!key || !value) return fail(ctx, RTGL_ERR_INVALID, "NULL argument");
+    if (!ctx->parts.empty()) { const int rc = rtgl_get_option(ctx->parts[0], key, value); return rc ? fail(ctx, rc, ctx->parts[0]->error) : RTGL_OK; }
     if (!strcmp(key, "kernel")) *value = ctx->opt_kernel;
     else if (!strcmp(key, "kernel_in_use")) *value = ctx->kernel_in_use;
     else if (!strcmp(key, "wf_rays")) *value = ctx->opt_wf_rays;
@@ -985,6 +1143,15 @@ extern "C" int rtgl_get_option(rtgl_context *ctx, const char *key, int *value)
     else if (!strcmp(key, "rng_state")) *value = ctx->opt_rng_state;
     else if (!strcmp(key, "counters")) *value = ctx->opt_counters;
     else if (!strcmp(key, "kernel_timing")) *value = ctx->opt_kernel_timing;
+    else if (!strcmp(key, "cand_region_pairs")) *value = (int)ctx->cand_region_pairs;      // kernel 4: current capacity of one wave's candidate region
+    else if (!strcmp(key, "device_mbytes")) {                                              // device memory held by this context (MiB, rounded up)
+        size_t b = (size_t)std::max(ctx->local_rows, 1) * ctx->width * 16;
+        b += (size_t)ctx->wave_capacity * (68 + 8) * 2 + (ctx->wave_multi ? (size_t)std::max(ctx->local_rows, 1) * ctx->width * 64 : 0);
+        b += ((size_t)ctx->cand_regions * ctx->cand_region_pairs) * 8 + (size_t)ctx->cand_regions * 4;
+        b += (size_t)ctx->n_tri_visits * (sizeof(TriEdges) + sizeof(TriPlane) + 4 + 112) + (size_t)ctx->n_vec4 * 16 + (size_t)ctx->env_faces * ctx->env_w * ctx->env_h * ctx->env_c;
+        if (ctx->d_rng) b += (size_t)std::max(ctx->local_rows, 1) * ctx->width * 16;
+        *value = (int)((b + (1u << 20) - 1) >> 20);
+    }
     else return fail(ctx, RTGL_ERR_INVALID, std::string("unknown option ") + key);
     return RTGL_OK;
 }

@@ -28,7 +28,7 @@ ABI_SYMBOLS = [
     "rtgl_clear_image", "rtgl_local_rows", "rtgl_local_row_to_global", "rtgl_device_image",
     "rtgl_bind_device_image", "rtgl_set_stream", "rtgl_get_counters", "rtgl_read_rng_state",
     "rtgl_set_option", "rtgl_get_option", "rtgl_last_frame_ms", "rtgl_last_frame_timing",
-    "rtgl_accumulated_timing", "rtgl_timing_reset",
+    "rtgl_accumulated_timing", "rtgl_timing_reset", "rtgl_create_multi", "rtgl_device_count", "rtgl_gather_tiles",
 ]
 
 
@@ -82,6 +82,9 @@ def load_library() -> C.CDLL:
     vp, u32, i = C.c_void_p, C.c_uint32, C.c_int
     L.rtgl_create.argtypes = [C.POINTER(vp), i, i, i]
     L.rtgl_create_tiled.argtypes = [C.POINTER(vp), i, i, i, i, i, i]
+    L.rtgl_create_multi.argtypes = [C.POINTER(vp), i, i, C.POINTER(i), i, i]
+    L.rtgl_device_count.argtypes = [vp]
+    L.rtgl_gather_tiles.argtypes = [vp]
     L.rtgl_destroy.argtypes = [vp]; L.rtgl_destroy.restype = None
     L.rtgl_last_error.argtypes = [vp]; L.rtgl_last_error.restype = C.c_char_p
     for name in ("rtgl_upload_spheres", "rtgl_upload_materials", "rtgl_upload_meshes", "rtgl_upload_vertices", "rtgl_upload_nodes"):
@@ -129,12 +132,18 @@ def _ptr(a):
 class Context:
     """One rtgl_context.  rank/world/strip_rows select row-strip tiling for multi-GPU runs."""
 
-    def __init__(self, width: int, height: int, device: int = 0, rank: int = 0, world: int = 1, strip_rows: int = 16):
+    def __init__(self, width: int, height: int, device: int = 0, rank: int = 0, world: int = 1, strip_rows: int = 16, devices=None):
+        """devices=[ordinals]: one single-process multi-device context (rtgl_create_multi) instead of a (rank, world) tile."""
         self.lib = load_library()
         self.width, self.height = int(width), int(height)
         self.rank, self.world, self.strip_rows = rank, world, strip_rows
         h = C.c_void_p()
-        rc = self.lib.rtgl_create_tiled(C.byref(h), width, height, device, rank, world, strip_rows)
+        if devices is not None:
+            self.rank, self.world = 0, 1
+            arr = (C.c_int * len(devices))(*devices)
+            rc = self.lib.rtgl_create_multi(C.byref(h), width, height, arr, len(devices), strip_rows)
+        else:
+            rc = self.lib.rtgl_create_tiled(C.byref(h), width, height, device, rank, world, strip_rows)
         if rc != 0:
             raise RtglError(f"rtgl_create failed ({rc}): {self.lib.rtgl_last_error(None).decode()}")
         self.h = h

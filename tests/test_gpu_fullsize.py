@@ -180,3 +180,34 @@ def test_c2_degenerate_group_floods_the_candidate_regions(rt, monkeypatch):
     img, cnt = run((("kernel", 4), ("mf_group_quads", 2)))
     assert cnt["candidates"] > 50_000_000
     assert (img.view(np.uint32) == ref.view(np.uint32)).all()
+
+
+@pytest.mark.parametrize("devices,strip", [([0, 0], 8), ([0, 0, 0], 16)])
+def test_multi_device_context_through_the_c_abi_matches_single_context(devices, strip, rt):
+    """rtgl_create_multi: one handle, several tiled contexts (here all on device 0 -- also the "two contexts in one process" case
+    of the per-device kernel attributes), gather by 2-D device copies into the assembler's image.  Uploads, frames, counters and the
+    image go through the ordinary entry points; the result equals the single-context render bit for bit."""
+    sc = rt.scenes
+    W, H = 328, 204                                   # 25.5 strips of 8 rows: the last strip is short
+    scene = sc.scene_mesh(30, 10, env_size=32)
+    base = sc.params_c2()
+    g = sc.GlibcRand(0)
+    plist = [base.replace(frames=f, random=g.rand()) for f in range(1, 4)]
+
+    def run(**kw):
+        ctx = rt.host.Context(W, H, **kw)
+        ctx.set_option("counters", 1)
+        ctx.upload_scene(scene)
+        for p in plist:
+            ctx.render(p)
+        img, cnt = ctx.read_image(), ctx.counters()
+        u8 = ctx.read_image_u8(flip=True)
+        ctx.close()
+        return img, cnt, u8
+
+    ref, cnt_ref, u8_ref = run()
+    img, cnt, u8 = run(devices=devices, strip_rows=strip)
+    assert img.shape == ref.shape
+    assert (img.view(np.uint32) == ref.view(np.uint32)).all()
+    assert (u8 == u8_ref).all()
+    assert cnt["paths"] == cnt_ref["paths"] and cnt["segments"] == cnt_ref["segments"]
