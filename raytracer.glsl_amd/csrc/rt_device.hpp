@@ -405,7 +405,7 @@ __device__ __forceinline__ int local_to_global_row(const ImageView &im, int lr)
     return (ls * im.world + im.rank) * im.strip_rows + within;
 }
 
-struct Counters { unsigned long long paths, segments, tri_tests, candidates, env_lookups; };
+struct Counters { unsigned long long paths, segments, tri_tests, candidates, env_lookups, culled_tests; };
 
 // running mean of main() (:561-568)
 __device__ __forceinline__ float4 accumulate_pixel(const FrameParams &P, f3 color, f3 prev)

@@ -54,6 +54,7 @@ struct alignas(16) MfGroup {
     float pad1;
 };
 
+struct MfCull;
 struct MfView {
     const MfGroup *groups; uint32_t n_groups;
     uint32_t group_quads;    // quads per group (power of two); storage is allocated in whole groups
@@ -65,6 +66,7 @@ struct MfView {
     // i.e. F~ = (e_hi + e_lo).cv_hi + (m_hi + m_lo).d_hi + m_hi.d_lo  (+ bias, -3e38 on padding rows, 0 otherwise)
     const uint4 *A;
     uint32_t *dbg_log;       // diagnostics only
+    const MfCull *cull;      // one record per quad (packet culling)
     const uint32_t *order;   // storage position -> visit index.  Triangles are stored in Morton order of their centroids
                              // so that the triangles of a group are neighbours (tight local bounds); hits are merged by VISIT
                              // index, so the reference's first-visited-wins tie rule (:349) is unaffected by the reordering
@@ -189,6 +191,94 @@ __device__ __forceinline__ float mf_margin(const MfGroup &G, float ncv, float no
     float cancel = 9.5367431640625e-07f * (__builtin_fmaf(G.E, no, G.P) * r.wd);              // 2^-20 (E|o'| + P)|d|
     float world = 9.5367431640625e-07f * __builtin_fmaf(G.E, r.wod, G.Pw * r.wd);             // 2^-20 (E|o||d| + Pw|d|)
     return (local + cancel) + (world + 1e-30f);
+}
+
+// ---- packet culling (the reference's disabled AABB cull, raytracer.glsl:258-270,288-292, done rigorously) ----------
+// A wave scans 128 rays against a chunk of quads (40 triangles each).  A quad may be skipped for the whole wave when EVERY ray of
+// the wave is certified to be rejected by the reference's own test for EVERY triangle of the quad.  "The ray misses the quad's
+// bounding volume" is not such a certificate: the reference tests LINES, and a line lying in (or within rounding noise of) the
+// plane of a far-away triangle has all three edge functions at +-noise, so the reference may accept it with an arbitrary t.  The
+// certificate therefore lives in edge-function space.  With N = (v1-v0) x (v2-v0), p = line /\ plane and beta_k the barycentric
+// coordinates of p, the exact edge functions are F_k = -(d.N) beta_k (F_0 = d.((o-v0) x e0) = d.((p-v0) x e0)), so
+//   * front facing (d.N < 0): p at distance >= delta from the triangle  =>  some beta_k <= -delta s / h_max, s = sin(smallest
+//     angle / 2), h_max the largest height (closest point on an edge: the edge's own coordinate; at a vertex: the normal cone of
+//     the vertex gives cos >= sin(angle/2) for one of the two edges)  =>  min_k F_k <= -|d.N| delta s / h_max;
+//   * back facing (d.N > 0): sum beta = 1  =>  max beta >= 1/3  =>  min_k F_k <= -(d.N)/3.
+// The reference rejects an edge whenever its exact value is <= -(7w E|o||d| + 6w Pw|d|), w = 2^-24 (mf_margin, part (2)); so
+//   |d^.N_T| min(1/3, delta s_T / h_T)  >=  2^-20 (E |o| + Pw)          for every triangle T of the quad, every ray of the wave
+// certifies the skip (d^ = d/|d|: both sides scale with |d|).  Per quad the record below bounds the left side from below for any
+// line that misses the quad's bounding sphere (C, R) by delta and whose direction makes |cos| >= cmin with every triangle normal
+// (the unit normals of the quad lie in the box [nlo, nhi]: interval arithmetic on D.n^ -- a bumpy height field spreads its
+// normals by +-50 degrees inside 40 triangles, far too much for a cone, but mostly across the viewing direction); per wave the
+// kernel bounds its rays by an origin sphere (O, ro) and a direction cone (D, sigma = max |d^ - D|):
+//   delta >= |(C-O) x D| - |C-O| sigma - ro - R,     cmin >= min |[D.n^]| - sigma  (0 not inside the interval),     |o| <= |O| + ro.
+// Degenerate or non-finite triangles make the record unusable (Nmin = 0 or NaN: the comparison fails, the quad is scanned).
+struct alignas(16) MfCull {
+    float cx, cy, cz, R;          // bounding sphere of the quad's vertices
+    float nlx, nly, nlz;          // box of the unit normals
+    float nhx, nhy, nhz;
+    float Nmin, shape;            // min |N_T|, min s_T / h_max,T
+    float E, Pw;                  // max |e_k|, max |v_a||v_b|  (the reference's own rounding, world coordinates)
+    float pad[2];
+};
+static_assert(sizeof(MfCull) == 64, "one LDS row of four uint4 per quad");
+
+__device__ __forceinline__ float wave_sum(float x) { for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off); return x; }
+
+// one wave per quad, one lane per triangle (storage order)
+__global__ void __launch_bounds__(64) prepare_cull_kernel(const float4 *__restrict__ vertices, const uint32_t *__restrict__ visit_tri,
+                                                          const uint32_t *__restrict__ order, uint32_t n_visits, uint32_t n_quads, MfCull *__restrict__ out)
+{
+    const uint32_t q = blockIdx.x, lane = threadIdx.x;
+    if (q >= n_quads) return;
+    const uint32_t pos = q * kMfQuadTris + lane;
+    const bool have = lane < (uint32_t)kMfQuadTris && pos < n_visits;
+    const float inf = __builtin_inff();
+    f3 w[3] = {mk(0.0f, 0.0f, 0.0f), mk(0.0f, 0.0f, 0.0f), mk(0.0f, 0.0f, 0.0f)};
+    if (have) { const uint32_t tri = visit_tri[order[pos]]; for (int k = 0; k < 3; ++k) { const float4 p = vertices[3 * (size_t)tri + k]; w[k] = mk(p.x, p.y, p.z); } }
+    f3 lo = mk(inf, inf, inf), hi = mk(-inf, -inf, -inf);
+    bool bad = false;
+    if (have) for (int k = 0; k < 3; ++k) {
+        lo = mk(fminf(lo.x, w[k].x), fminf(lo.y, w[k].y), fminf(lo.z, w[k].z));
+        hi = mk(fmaxf(hi.x, w[k].x), fmaxf(hi.y, w[k].y), fmaxf(hi.z, w[k].z));
+        bad |= !(fabsf(w[k].x) < 1e18f) || !(fabsf(w[k].y) < 1e18f) || !(fabsf(w[k].z) < 1e18f);
+    }
+    lo = mk(wave_min(lo.x), wave_min(lo.y), wave_min(lo.z));
+    hi = mk(wave_max(hi.x), wave_max(hi.y), wave_max(hi.z));
+    const f3 c = mk(0.5f * lo.x + 0.5f * hi.x, 0.5f * lo.y + 0.5f * hi.y, 0.5f * lo.z + 0.5f * hi.z);
+    float R = 0.0f, E = 0.0f, Pw = 0.0f, Nmin = inf, shape = inf;
+    f3 nh = mk(0.0f, 0.0f, 0.0f);
+    if (have) {
+        const f3 e0 = w[1] - w[0], e1 = w[2] - w[1], e2 = w[0] - w[2];
+        const f3 N = cross3(e0, mk(-e2.x, -e2.y, -e2.z));                    // (v1 - v0) x (v2 - v0)
+        const float nn = __builtin_sqrtf(dot3(N, N));
+        const float l0 = __builtin_sqrtf(dot3(e0, e0)), l1 = __builtin_sqrtf(dot3(e1, e1)), l2 = __builtin_sqrtf(dot3(e2, e2));
+        for (int k = 0; k < 3; ++k) { const f3 r = w[k] - c; R = fmaxf(R, __builtin_sqrtf(dot3(r, r))); }
+        E = fmaxf(l0, fmaxf(l1, l2));
+        const float a0 = __builtin_sqrtf(dot3(w[0], w[0])), a1 = __builtin_sqrtf(dot3(w[1], w[1])), a2 = __builtin_sqrtf(dot3(w[2], w[2]));
+        Pw = fmaxf(a0 * a1, fmaxf(a1 * a2, a2 * a0));
+        Nmin = nn;
+        nh = (nn > 0.0f) ? mk(N.x / nn, N.y / nn, N.z / nn) : mk(0.0f, 0.0f, 0.0f);
+        // smallest interior angle: cos at the vertex between the two edges leaving it; sin(angle / 2) = sqrt((1 - cos) / 2)
+        const float c0 = -dot3(e0, e2) / (l0 * l2), c1 = -dot3(e1, e0) / (l1 * l0), c2 = -dot3(e2, e1) / (l2 * l1);
+        const float cmax = fminf(1.0f, fmaxf(c0, fmaxf(c1, c2)));
+        const float s = __builtin_sqrtf(fmaxf(0.0f, 0.5f * (1.0f - cmax)));
+        const float lmin = fminf(l0, fminf(l1, l2));
+        shape = (nn > 0.0f) ? 0.999f * s * lmin / nn : 0.0f;                 // s / h_max, h_max = |N| / shortest edge
+        if (!(shape == shape)) shape = 0.0f;
+    }
+    R = wave_max(R); E = wave_max(E); Pw = wave_max(Pw); Nmin = wave_min(Nmin); shape = wave_min(shape);
+    f3 nl = have ? nh : mk(inf, inf, inf), nu = have ? nh : mk(-inf, -inf, -inf);
+    nl = mk(wave_min(nl.x), wave_min(nl.y), wave_min(nl.z)); nu = mk(wave_max(nu.x), wave_max(nu.y), wave_max(nu.z));
+    bad = __any(bad);
+    if (lane != 0) return;
+    MfCull rec;
+    rec.cx = c.x; rec.cy = c.y; rec.cz = c.z; rec.R = R * 1.0001f + 1e-30f;
+    rec.nlx = nl.x - 1e-6f; rec.nly = nl.y - 1e-6f; rec.nlz = nl.z - 1e-6f; rec.nhx = nu.x + 1e-6f; rec.nhy = nu.y + 1e-6f; rec.nhz = nu.z + 1e-6f;
+    rec.Nmin = bad ? 0.0f : Nmin * 0.999f; rec.shape = bad ? 0.0f : shape;
+    rec.E = E * 1.001f; rec.Pw = Pw * 1.001f;
+    rec.pad[0] = rec.pad[1] = 0.0f;
+    out[q] = rec;
 }
 
 }  // namespace rt

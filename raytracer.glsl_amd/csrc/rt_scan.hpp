@@ -124,7 +124,7 @@ struct SoloCfg {
 
 template <bool kCount>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
-scan_solo_kernel(SceneView sc, WaveBuffers wb, MfView mf, uint32_t bounce, uint32_t chunk_quads, Counters *__restrict__ counters, int debug_skip_exact)
+scan_solo_kernel(SceneView sc, WaveBuffers wb, MfView mf, uint32_t bounce, uint32_t chunk_quads, Counters *__restrict__ counters, int debug_skip_exact, int cull)
 {
     using Cfg = SoloCfg;
     constexpr int S = kSoloSets;
@@ -160,8 +160,14 @@ scan_solo_kernel(SceneView sc, WaveBuffers wb, MfView mf, uint32_t bounce, uint3
 #pragma unroll
             for (int k = 0; k < 8; ++k) { const uint32_t i = i0 + (uint32_t)k * 256u; if (i < n16) lds_tiles[i] = v[k]; }
         }
+        // the chunk's cull records behind the tiles (and the two spare rows): one 64-byte record per quad
+        const uint4 *csrc = reinterpret_cast<const uint4 *>(mf.cull + q_begin);
+        uint4 *cdst = lds_tiles + (size_t)(chunk_quads * kMfQuadTiles + 2u) * 64u;
+        if (threadIdx.x < (q_end - q_begin) * 4u) cdst[threadIdx.x] = csrc[threadIdx.x];
         __syncthreads();
     }
+    const MfCull *lds_cull = reinterpret_cast<const MfCull *>(lds_tiles + (size_t)(chunk_quads * kMfQuadTiles + 2u) * 64u);
+    unsigned long long c_culled = 0;
     RT_STAMP(ts_staged);
     RT_STAMP_ADD(tt_stage, ts_begin, ts_staged);
     uint32_t *queue = lds_queue + wave * Cfg::kQueue;
@@ -202,6 +208,58 @@ scan_solo_kernel(SceneView sc, WaveBuffers wb, MfView mf, uint32_t bounce, uint3
         // the next block's rays travel while this one is scanned (one wave per SIMD: nothing else would hide the round trip)
         if (base + gridDim.x * Cfg::kRaysPerBlock < n_rays) fetch_rays(base + gridDim.x * Cfg::kRaysPerBlock);
 
+        // ---- packet culling (rt_mfma.hpp, MfCull): which quads of the chunk can this wave's 128 rays not be rejected for?
+        uint32_t keep = 0xFFFFFFFFu >> (32u - (q_end - q_begin));              // bit q: quad q of the chunk must be scanned
+        if (cull) {
+            const float inf = __builtin_inff();
+            f3 olo = mk(inf, inf, inf), ohi = mk(-inf, -inf, -inf), dlo = olo, dhi = ohi;
+            f3 dh[S];
+            bool usable = true;                                                   // every valid ray has a finite origin and a normalisable direction
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                const MfRay &r = ray[s];
+                const float dl = __builtin_sqrtf(dot3(r.d, r.d));
+                dh[s] = mk(r.d.x / dl, r.d.y / dl, r.d.z / dl);
+                if (r.valid) {
+                    usable &= (dl > 0.0f) && (dl < inf) && (fabsf(r.o.x) < 1e18f) && (fabsf(r.o.y) < 1e18f) && (fabsf(r.o.z) < 1e18f);
+                    olo = mk(fminf(olo.x, r.o.x), fminf(olo.y, r.o.y), fminf(olo.z, r.o.z)); ohi = mk(fmaxf(ohi.x, r.o.x), fmaxf(ohi.y, r.o.y), fmaxf(ohi.z, r.o.z));
+                    dlo = mk(fminf(dlo.x, dh[s].x), fminf(dlo.y, dh[s].y), fminf(dlo.z, dh[s].z)); dhi = mk(fmaxf(dhi.x, dh[s].x), fmaxf(dhi.y, dh[s].y), fmaxf(dhi.z, dh[s].z));
+                }
+            }
+            olo = mk(wave_min(olo.x), wave_min(olo.y), wave_min(olo.z)); ohi = mk(wave_max(ohi.x), wave_max(ohi.y), wave_max(ohi.z));
+            dlo = mk(wave_min(dlo.x), wave_min(dlo.y), wave_min(dlo.z)); dhi = mk(wave_max(dhi.x), wave_max(dhi.y), wave_max(dhi.z));
+            const f3 O = mk(0.5f * olo.x + 0.5f * ohi.x, 0.5f * olo.y + 0.5f * ohi.y, 0.5f * olo.z + 0.5f * ohi.z);
+            f3 D = mk(0.5f * dlo.x + 0.5f * dhi.x, 0.5f * dlo.y + 0.5f * dhi.y, 0.5f * dlo.z + 0.5f * dhi.z);
+            const float Dl = __builtin_sqrtf(dot3(D, D));
+            D = mk(D.x / Dl, D.y / Dl, D.z / Dl);
+            float ro = 0.0f, sigma = 0.0f;
+#pragma unroll
+            for (int s = 0; s < S; ++s)
+                if (ray[s].valid) {
+                    const f3 eo = ray[s].o - O, ed = dh[s] - D;
+                    ro = fmaxf(ro, __builtin_sqrtf(dot3(eo, eo))); sigma = fmaxf(sigma, __builtin_sqrtf(dot3(ed, ed)));
+                }
+            ro = wave_max(ro) * 1.0001f + 1e-30f; sigma = wave_max(sigma) * 1.0001f + 1e-6f;
+            usable = !__any(!usable) && (Dl > 0.25f);                             // (an empty wave has ro = sigma ~ 0 and culls everything it can: it has no rays)
+            const float On = __builtin_sqrtf(dot3(O, O)) * 1.0001f + ro;          // >= |o| of every ray
+            bool skip = false;
+            if (usable && (uint32_t)lane < q_end - q_begin) {
+                const MfCull c = lds_cull[lane];
+                const f3 w = mk(c.cx, c.cy, c.cz) - O;
+                const float L = __builtin_sqrtf(dot3(w, w)) * 1.0001f;
+                const f3 cr = cross3(w, D);
+                const float crn = __builtin_sqrtf(dot3(cr, cr));
+                const float delta = (crn * 0.9999f - L * sigma) - (ro + c.R) - 1e-5f * (L + ro + c.R);      // the lines miss the sphere by at least this
+                // range of D.n^ over the box of the quad's unit normals; |d^.n^ - D.n^| <= sigma
+                const float plo = (fminf(D.x * c.nlx, D.x * c.nhx) + fminf(D.y * c.nly, D.y * c.nhy)) + fminf(D.z * c.nlz, D.z * c.nhz);
+                const float phi = (fmaxf(D.x * c.nlx, D.x * c.nhx) + fmaxf(D.y * c.nly, D.y * c.nhy)) + fmaxf(D.z * c.nlz, D.z * c.nhz);
+                const float cmin = ((plo > 0.0f) ? plo : ((phi < 0.0f) ? -phi : -1.0f)) - sigma - 1e-5f;
+                const float lhs = (c.Nmin * cmin) * fminf(0.3333f, delta * c.shape) * 0.99f;
+                const float rhs = 9.5367431640625e-07f * __builtin_fmaf(c.E, On, c.Pw) * 1.01f;      // 2^-20 (E |o| + Pw): the reference's own rounding (mf_margin)
+                skip = (delta > 0.0f) && (cmin > 0.0f) && (c.Nmin > 0.0f) && (lhs > 0.0f) && (lhs >= rhs);    // any NaN: false
+            }
+            keep &= ~(uint32_t)__builtin_amdgcn_ballot_w64(skip);
+        }
         uint32_t qn = 0, n_total = 0;                            // wave-uniform
         const uint32_t wave_slot0 = base + (uint32_t)(wave * S) * 32u;
         auto flush = [&]() {
@@ -259,11 +317,15 @@ scan_solo_kernel(SceneView sc, WaveBuffers wb, MfView mf, uint32_t bounce, uint3
         RT_STAMP_ADD(tt_rays, ts_iter, ts_rays);
 
         // segments = runs of tiles that share one group (local origin + bounds); a chunk may start or end inside a group
-        for (uint32_t t0 = 0; t0 < n_tiles;) {
+        for (uint32_t ts0 = 0; ts0 < n_tiles;) {
             RT_STAMP(ts_g0);
-            const uint32_t q = q_begin + t0 / kMfQuadTiles;
+            const uint32_t q = q_begin + ts0 / kMfQuadTiles;
             const uint32_t g = q >> group_shift;
-            const uint32_t t1 = min(n_tiles, (((g + 1u) << group_shift) - q_begin) * kMfQuadTiles);
+            const uint32_t ts1 = min(n_tiles, (((g + 1u) << group_shift) - q_begin) * kMfQuadTiles);
+            // quads of this segment the wave still has to scan; a segment that is culled altogether costs nothing, not even its setup
+            const uint32_t qa = ts0 / kMfQuadTiles, nq = (ts1 - ts0) / kMfQuadTiles;
+            uint32_t seg = keep & ((nq >= 32u ? 0xFFFFFFFFu : ((1u << nq) - 1u)) << qa);
+            if (seg == 0u) { ts0 = ts1; continue; }
             const ConstFloats gp = groups_k + (size_t)g * (sizeof(MfGroup) / 4);
             MfGroup G;
             G.cx = gp[0]; G.cy = gp[1]; G.cz = gp[2]; G.E = gp[3]; G.Ml = gp[4]; G.Pw = gp[5]; G.P = gp[6]; G.pad1 = 0.0f;
@@ -285,14 +347,18 @@ scan_solo_kernel(SceneView sc, WaveBuffers wb, MfView mf, uint32_t bounce, uint3
             }
             B0 = Bs[0]; B1 = Bs[1]; B2 = Bs[2]; B3 = Bs[3];
             th0 = ths[0]; th1 = ths[1]; th2 = ths[2]; th3 = ths[3];
+            while (seg != 0u) {
+            // next run of consecutive quads to scan: tiles [t0, t1)
+            const uint32_t qs = (uint32_t)__builtin_ctz(seg), inv = ~(seg >> qs);
+            const uint32_t run = inv ? (uint32_t)__builtin_ctz(inv) : 32u - qs;
+            seg &= ~((run >= 32u ? 0xFFFFFFFFu : ((1u << run) - 1u)) << qs);
+            const uint32_t t0 = qs * kMfQuadTiles, t1 = (qs + run) * kMfQuadTiles;
             // prologue: the products of the segment's first tile.  The tile rows of a trip are read during the trip before; the two rows
             // behind the chunk's last tile are allocated (and never used).
             const uint4 *row = lds_tiles + (size_t)t0 * 64u + l_lane;
             auto tile_row = [&]() { const uint4 r = *row; row += 64; return u32x4{r.x, r.y, r.z, r.w}; };
             u32x4 ap = tile_row(), ay = tile_row(), ax = tile_row();
             RT_PRODUCTS_X(ap);
-            RT_STAMP(ts_g1);
-            RT_STAMP_ADD(tt_group, ts_g0, ts_g1);
             // steady state: two stages per trip (tile t -> Y beside the examination of tile t-1, tile t+1 -> X beside the examination
             // of tile t), so that X and Y swap roles without moves
             uint32_t t = t0 + 1u;
@@ -315,9 +381,10 @@ scan_solo_kernel(SceneView sc, WaveBuffers wb, MfView mf, uint32_t bounce, uint3
                 RT_EXAMINE_X();
                 park(t - 1u, MA0, MA1, MA2, MA3);
             }
-            t0 = t1;
+            }
+            ts0 = ts1;
             RT_STAMP(ts_g2);
-            RT_STAMP_ADD(tt_steady, ts_g1, ts_g2);
+            RT_STAMP_ADD(tt_steady, ts_g0, ts_g2);
         }
         RT_STAMP(ts_f0);
         flush();
@@ -327,6 +394,11 @@ scan_solo_kernel(SceneView sc, WaveBuffers wb, MfView mf, uint32_t bounce, uint3
         tt_iters++;
 #endif
         c_cand_total += (lane == 0) ? n_total : 0u;
+        if (kCount && lane == 0) {
+            const uint32_t culled = (uint32_t)__builtin_popcount(~keep & (0xFFFFFFFFu >> (32u - (q_end - q_begin))));
+            const uint32_t rays_here = wave_slot0 < n_rays ? min(128u, n_rays - wave_slot0) : 0u;
+            c_culled += (unsigned long long)culled * kMfQuadTris * rays_here;
+        }
     }
 #ifdef RT_SOLO_STAMPS
     if (lane == 0 && mf.dbg_log) {
@@ -341,6 +413,7 @@ scan_solo_kernel(SceneView sc, WaveBuffers wb, MfView mf, uint32_t bounce, uint3
     if (lane == 0 && appended > (unsigned long long)*wb.cand_peak) atomicMax(wb.cand_peak, (uint32_t)(appended < 0xFFFFFFF0ull ? appended : 0xFFFFFFF0ull));   // (racy pre-check: only saves atomics)
     if (kCount) {
         atomicAdd(&counters->candidates, c_cand_total);
+        if (c_culled) atomicAdd(&counters->culled_tests, c_culled);
         if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&counters->tri_tests, (unsigned long long)n_rays * (v_chunk_end - v_chunk_begin));
     }
 }

@@ -178,7 +178,7 @@ struct rtgl_context {
 
     // bounce-wavefront pipeline buffers
     float2 *d_group_bounds = nullptr;
-    MfGroup *d_mf_groups = nullptr; uint4 *d_mf_A = nullptr; uint32_t *d_mf_order = nullptr; uint32_t n_mf_groups = 0, mf_group_quads = 32; uint32_t *d_dbg_log = nullptr;   // bf16 matrix-core broad phase
+    MfGroup *d_mf_groups = nullptr; MfCull *d_mf_cull = nullptr; uint4 *d_mf_A = nullptr; uint32_t *d_mf_order = nullptr; uint32_t n_mf_groups = 0, mf_group_quads = 32; uint32_t *d_dbg_log = nullptr;   // bf16 matrix-core broad phase
     void *d_wave = nullptr; size_t wave_capacity = 0; bool wave_multi = false;   // queues (+ per-pixel state when u_samples > 1)
     uint32_t *d_counts = nullptr; uint32_t counts_capacity = 0;
     uint32_t *h_counts = nullptr;            // pinned: ray counts per bounce of the most recent finished frame
@@ -205,7 +205,7 @@ struct rtgl_context {
     bool tris_dirty = false, visits_dirty = false;
     FrameParams params{};
     bool have_params = false;
-    int opt_kernel = RTGL_KERNEL_WAVEFRONT_MFMA_SOLO, opt_rng_state = 0, opt_counters = 0, opt_kernel_timing = 0, opt_wf_rays = 4, opt_wf_mode = kLds, opt_wf_chunk = 256, opt_wf_early = 0, opt_wf_packed = 0, opt_mf_chunk_quads = 32, opt_mf_group_quads = 32, opt_debug_skip_exact = 0;
+    int opt_kernel = RTGL_KERNEL_WAVEFRONT_MFMA_SOLO, opt_rng_state = 0, opt_counters = 0, opt_kernel_timing = 0, opt_wf_rays = 4, opt_wf_mode = kLds, opt_wf_chunk = 256, opt_wf_early = 0, opt_wf_packed = 0, opt_mf_chunk_quads = 32, opt_mf_group_quads = 32, opt_cull = 1, opt_debug_skip_exact = 0;
 };
 
 static int fail(rtgl_context *ctx, int code, const std::string &msg)
@@ -298,7 +298,7 @@ extern "C" void rtgl_destroy(rtgl_context *ctx)
 #endif
     void *ptrs[] = { ctx->d_spheres, ctx->d_materials, ctx->d_vertices, ctx->d_sphere_visits, ctx->d_edges, ctx->d_planes,
                      ctx->d_env, ctx->d_image_own, ctx->d_rng, ctx->d_counters, ctx->d_u8, ctx->d_group_bounds, ctx->d_wave, ctx->d_counts, ctx->d_mf_groups, ctx->d_mf_A, ctx->d_mf_order,
-                     ctx->d_dbg_log, ctx->d_cand };
+                     ctx->d_dbg_log, ctx->d_cand, ctx->d_mf_cull };
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (hipEvent_t e : ctx->kev) (void)hipEventDestroy(e);
     if (ctx->h_counts) (void)hipHostFree(ctx->h_counts);
@@ -567,6 +567,7 @@ static int rebuild_triangles(rtgl_context *ctx)
         if (ctx->d_mf_groups) { HIPCHK(ctx, hipFree(ctx->d_mf_groups)); ctx->d_mf_groups = nullptr; }
         if (ctx->d_mf_A) { HIPCHK(ctx, hipFree(ctx->d_mf_A)); ctx->d_mf_A = nullptr; }
         if (ctx->d_mf_order) { HIPCHK(ctx, hipFree(ctx->d_mf_order)); ctx->d_mf_order = nullptr; }
+        if (ctx->d_mf_cull) { HIPCHK(ctx, hipFree(ctx->d_mf_cull)); ctx->d_mf_cull = nullptr; }
         ctx->mf_group_quads = (uint32_t)ctx->opt_mf_group_quads;
         const uint32_t group_tris = ctx->mf_group_quads * kMfQuadTris;
         ctx->n_mf_groups = (ctx->n_tri_visits + group_tris - 1) / group_tris;
@@ -580,6 +581,13 @@ static int rebuild_triangles(rtgl_context *ctx)
         HIPCHK(ctx, hipMemsetAsync(ctx->d_mf_A, 0, a_bytes, ctx->stream));
         hipLaunchKernelGGL(prepare_mfma_kernel, dim3(ctx->n_mf_groups), dim3(64), 0, ctx->stream, ctx->d_vertices, d_visit,
                            ctx->d_mf_order, ctx->n_tri_visits, ctx->n_mf_groups, ctx->mf_group_quads, ctx->d_mf_groups, ctx->d_mf_A);
+        HIPCHK(ctx, hipGetLastError());
+        // packet-culling records, one per quad of the storage order (+ one group's worth of slack: a chunk copies whole records)
+        const uint32_t n_quads_alloc = ctx->n_mf_groups * ctx->mf_group_quads + 32u;
+        HIPCHK(ctx, hipMalloc((void **)&ctx->d_mf_cull, (size_t)n_quads_alloc * sizeof(MfCull)));
+        HIPCHK(ctx, hipMemsetAsync(ctx->d_mf_cull, 0, (size_t)n_quads_alloc * sizeof(MfCull), ctx->stream));
+        hipLaunchKernelGGL(prepare_cull_kernel, dim3(ctx->n_mf_groups * ctx->mf_group_quads), dim3(64), 0, ctx->stream, ctx->d_vertices, d_visit,
+                           ctx->d_mf_order, ctx->n_tri_visits, ctx->n_mf_groups * ctx->mf_group_quads, ctx->d_mf_cull);
         HIPCHK(ctx, hipGetLastError());
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
         HIPCHK(ctx, hipFree(d_visit));
@@ -709,11 +717,11 @@ static int launch_intersect_solo(rtgl_context *ctx, const SceneView &sc, uint32_
     const uint32_t est = estimate_rays(ctx, n0, bounce), blocks_x_all = (est + Cfg::kRaysPerBlock - 1u) / Cfg::kRaysPerBlock;
     // one block per CU in total: with more, the surplus runs as a second, mostly empty round
     const uint32_t blocks_x = std::max(1u, std::min(blocks_x_all, (uint32_t)ctx->n_cus / chunks));
-    const size_t lds = std::max<size_t>(((size_t)chunk_quads * kMfQuadTiles + 2) * 1024, 96 * 1024);   // + the two rows read a trip ahead behind the last tile; > half of the CU's LDS with the static queue: one block per CU
+    const size_t lds = std::max<size_t>(((size_t)chunk_quads * kMfQuadTiles + 2) * 1024 + (size_t)chunk_quads * sizeof(MfCull), 96 * 1024);   // + the two rows read a trip ahead behind the last tile; > half of the CU's LDS with the static queue: one block per CU
 #ifdef RT_SOLO_STAMPS
     if (!ctx->d_dbg_log) { HIPCHK(ctx, hipMalloc((void **)&ctx->d_dbg_log, (size_t)(2 + (2u << 22)) * 4)); HIPCHK(ctx, hipMemsetAsync(ctx->d_dbg_log, 0, 16 * 8 * 64, ctx->stream)); }
 #endif
-    MfView mf{ctx->d_mf_groups, ctx->n_mf_groups, gq, n_quads, ctx->d_mf_A, ctx->d_dbg_log, ctx->d_mf_order};
+    MfView mf{ctx->d_mf_groups, ctx->n_mf_groups, gq, n_quads, ctx->d_mf_A, ctx->d_dbg_log, ctx->d_mf_cull, ctx->d_mf_order};
     if (!ctx->solo_attr_set) {
         // allow the whole LDS of a CU (160 KB) minus the kernel's static share as dynamic shared memory.  The attribute belongs to the
         // (function, device) pair, so it is raised once per context -- a context is bound to one device -- not once per process.
@@ -726,10 +734,12 @@ static int launch_intersect_solo(rtgl_context *ctx, const SceneView &sc, uint32_
         ctx->solo_attr_set = true;
     }
     dim3 grid(blocks_x, chunks);
+    // packet culling pays where the 128 rays of a wave are coherent: the camera rays (option "cull": 0 never, 1 bounce 0 (default), 2 every bounce)
+    const int cull = ctx->opt_cull == 2 || (ctx->opt_cull == 1 && bounce == 0);
     if (ctx->opt_counters)
-        hipLaunchKernelGGL((scan_solo_kernel<true>), grid, dim3(256), lds, ctx->stream, sc, ctx->wb, mf, bounce, chunk_quads, ctx->d_counters, ctx->opt_debug_skip_exact);
+        hipLaunchKernelGGL((scan_solo_kernel<true>), grid, dim3(256), lds, ctx->stream, sc, ctx->wb, mf, bounce, chunk_quads, ctx->d_counters, ctx->opt_debug_skip_exact, cull);
     else
-        hipLaunchKernelGGL((scan_solo_kernel<false>), grid, dim3(256), lds, ctx->stream, sc, ctx->wb, mf, bounce, chunk_quads, ctx->d_counters, ctx->opt_debug_skip_exact);
+        hipLaunchKernelGGL((scan_solo_kernel<false>), grid, dim3(256), lds, ctx->stream, sc, ctx->wb, mf, bounce, chunk_quads, ctx->d_counters, ctx->opt_debug_skip_exact, cull);
     HIPCHK(ctx, hipGetLastError());
     hipLaunchKernelGGL(narrow_phase_kernel, dim3(blocks_x * chunks * 4u), dim3(256), 0, ctx->stream, sc, ctx->wb, mf, bounce, blocks_x * chunks * 4u);
     return RTGL_OK;
@@ -1046,7 +1056,7 @@ extern "C" int rtgl_get_counters(rtgl_context *ctx, rtgl_counters *out)
         for (rtgl_context *part : ctx->parts) {
             rtgl_counters c; const int rc = rtgl_get_counters(part, &c);
             if (rc) return fail(ctx, rc, part->error);
-            out->paths += c.paths; out->segments += c.segments; out->triangle_tests += c.triangle_tests; out->candidates += c.candidates; out->env_lookups += c.env_lookups;
+            out->paths += c.paths; out->segments += c.segments; out->triangle_tests += c.triangle_tests; out->candidates += c.candidates; out->env_lookups += c.env_lookups; out->culled_tests += c.culled_tests;
         }
         return RTGL_OK;
     }
@@ -1055,7 +1065,7 @@ extern "C" int rtgl_get_counters(rtgl_context *ctx, rtgl_counters *out)
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     memset(out, 0, sizeof *out);
     out->paths = c.paths; out->segments = c.segments; out->triangle_tests = c.tri_tests;
-    out->candidates = c.candidates; out->env_lookups = c.env_lookups;
+    out->candidates = c.candidates; out->env_lookups = c.env_lookups; out->culled_tests = c.culled_tests;
     return RTGL_OK;
 }
 
@@ -1103,6 +1113,9 @@ extern "C" int rtgl_set_option(rtgl_context *ctx, const char *key, int value)
     } else if (!strcmp(key, "mf_chunk_quads")) {
         if (value < 1 || (uint32_t)value > kMfMaxChunkQuads) return fail(ctx, RTGL_ERR_INVALID, "mf_chunk_quads must be in [1, 32]");
         ctx->opt_mf_chunk_quads = value;
+    } else if (!strcmp(key, "cull")) {
+        if (value < 0 || value > 2) return fail(ctx, RTGL_ERR_INVALID, "cull must be 0 (off), 1 (camera rays) or 2 (every bounce)");
+        ctx->opt_cull = value;
     } else if (!strcmp(key, "mf_group_quads")) {
         if (value < 1 || value > (int)kMfMaxGroupQuads || (value & (value - 1))) return fail(ctx, RTGL_ERR_INVALID, "mf_group_quads must be a power of two in [1, 64]");
         if (value != ctx->opt_mf_group_quads) ctx->tris_dirty = true;                          // local origins and A tiles are per group
@@ -1140,6 +1153,7 @@ extern "C" int rtgl_get_option(rtgl_context *ctx, const char *key, int *value)
     else if (!strcmp(key, "mf_sets")) *value = kSoloSets;
     else if (!strcmp(key, "mf_chunk_quads")) *value = ctx->opt_mf_chunk_quads;
     else if (!strcmp(key, "mf_group_quads")) *value = ctx->opt_mf_group_quads;
+    else if (!strcmp(key, "cull")) *value = ctx->opt_cull;
     else if (!strcmp(key, "rng_state")) *value = ctx->opt_rng_state;
     else if (!strcmp(key, "counters")) *value = ctx->opt_counters;
     else if (!strcmp(key, "kernel_timing")) *value = ctx->opt_kernel_timing;

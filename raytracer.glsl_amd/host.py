@@ -48,7 +48,7 @@ class CFrameParams(C.Structure):
 class CCounters(C.Structure):
     """rtgl_counters"""
     _fields_ = [("paths", C.c_uint64), ("segments", C.c_uint64), ("triangle_tests", C.c_uint64),
-                ("candidates", C.c_uint64), ("env_lookups", C.c_uint64), ("reserved", C.c_uint64 * 3)]
+                ("candidates", C.c_uint64), ("env_lookups", C.c_uint64), ("culled_tests", C.c_uint64), ("reserved", C.c_uint64 * 2)]
 
 
 class CFrameTiming(C.Structure):
@@ -266,7 +266,7 @@ class Context:
     def counters(self) -> dict:
         c = CCounters()
         self._chk(self.lib.rtgl_get_counters(self.h, C.byref(c)))
-        return {k: int(getattr(c, k)) for k in ("paths", "segments", "triangle_tests", "candidates", "env_lookups")}
+        return {k: int(getattr(c, k)) for k in ("paths", "segments", "triangle_tests", "candidates", "env_lookups", "culled_tests")}
 
     def read_rng_state(self) -> np.ndarray:
         out = np.zeros((self.local_rows, self.width, 4), np.uint32)

@@ -211,3 +211,19 @@ def test_multi_device_context_through_the_c_abi_matches_single_context(devices, 
     assert (img.view(np.uint32) == ref.view(np.uint32)).all()
     assert (u8 == u8_ref).all()
     assert cnt["paths"] == cnt_ref["paths"] and cnt["segments"] == cnt_ref["segments"]
+
+
+@pytest.mark.parametrize("cfg_name,cull", [("C2", 1), ("C2", 2), ("C5", 1)])
+def test_packet_culling_skips_most_camera_ray_tests_and_changes_nothing(cfg_name, cull, rt):
+    """Packet culling (rt_mfma.hpp MfCull): a wave skips the quads for which every one of its 128 rays is certified to be rejected
+    by the reference's own edge test.  On the camera-ray bounce most (wave, quad) pairs go; the image must equal the uncalled scan
+    (kernel 4 with cull = 0) and the fp32 scan bit for bit."""
+    a, cnt_a, _, scene, _ = render(rt, cfg_name, frames=2, options=(("kernel", 4), ("cull", cull)), counters=True)
+    b, cnt_b, _, _, _ = render(rt, cfg_name, frames=2, options=(("kernel", 4), ("cull", 0)), counters=True)
+    assert (a.view(np.uint32) == b.view(np.uint32)).all()
+    assert cnt_b["culled_tests"] == 0 and cnt_a["triangle_tests"] == cnt_b["triangle_tests"] and cnt_a["segments"] == cnt_b["segments"]
+    px = cnt_a["paths"]
+    assert cnt_a["culled_tests"] > 0.8 * px * scene.n_triangles          # > 80 % of the camera-ray bounce
+    if cfg_name == "C2":
+        c = render(rt, cfg_name, frames=2, options=(("kernel", 2),))[0]
+        assert (a.view(np.uint32) == c.view(np.uint32)).all()

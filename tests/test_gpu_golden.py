@@ -39,7 +39,7 @@ def test_matrix_core_broad_phase_small_chunks_matches_reference_shader_output(pa
     """kernel 4 with chunks and groups small enough that the small golden meshes span several of each (a chunk of 3 quads cuts
     groups of 2 in the middle: segments of one and two quads, odd and even tile counts)."""
     meta, scene, frames, expected = load_case(path, rt)
-    img = render_case(rt, meta, scene, frames, options=(("kernel", 4), ("mf_chunk_quads", 3), ("mf_group_quads", 2)))
+    img = render_case(rt, meta, scene, frames, options=(("kernel", 4), ("mf_chunk_quads", 3), ("mf_group_quads", 2), ("cull", 0)))
     neq = (img.view(np.uint32) != expected.view(np.uint32)).any(axis=2)
     assert not neq.any(), f"{int(neq.sum())} of {neq.size} pixels differ from the reference shader's output"
 
@@ -48,7 +48,7 @@ def test_matrix_core_broad_phase_small_chunks_matches_reference_shader_output(pa
 def test_one_wave_per_simd_scan_matches_reference_shader_output(path, rt):
     """kernel 4 with one-quad groups and one-quad chunks (every segment is a prologue, one trip and an epilogue) -- every golden case."""
     meta, scene, frames, expected = load_case(path, rt)
-    img = render_case(rt, meta, scene, frames, options=(("kernel", 4), ("mf_chunk_quads", 1), ("mf_group_quads", 1)))
+    img = render_case(rt, meta, scene, frames, options=(("kernel", 4), ("mf_chunk_quads", 1), ("mf_group_quads", 1), ("cull", 2)))
     assert (img.view(np.uint32) == expected.view(np.uint32)).all()
 
 

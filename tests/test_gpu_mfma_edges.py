@@ -9,7 +9,7 @@ from test_gpu_parity import assert_bit_exact, run_both
 
 pytestmark = pytest.mark.gpu
 
-SCANS = [(4, 16, 32), (4, 1, 3), (4, 32, 32), (2, 1, 4), (0, 0, 1), (4, 1, 1), (4, 4, 5)]      # default and small groups / chunks of the matrix scan, fp32 scan, megakernel
+SCANS = [(4, 16, 32, 2), (4, 1, 3), (4, 32, 32), (2, 1, 4), (0, 0, 1), (4, 1, 1, 2), (4, 4, 5)]      # default and small groups / chunks of the matrix scan, fp32 scan, megakernel
 
 
 def scene_with(rt, vertices, spheres=True, env=32):

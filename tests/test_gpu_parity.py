@@ -8,7 +8,7 @@ pytestmark = pytest.mark.gpu
 
 # (kernel, wf_mode, wf_rays): megakernel, wavefront with scalar-fed / LDS-tiled triangle pass
 VARIANTS = [(0, 0, 1), (1, 0, 1), (1, 0, 4), (1, 1, 2), (1, 1, 4), (2, 0, 1), (2, 0, 4), (2, 0, 8), (2, 1, 1), (2, 1, 2), (2, 1, 4), (2, 1, 8),
-            (4, 1, 3), (4, 4, 3), (4, 2, 1), (4, 16, 32), (4, 1, 32), (4, 32, 32), (4, 8, 5)]   # kernel 4 = bf16 matrix-core broad phase, one wave per SIMD: (4, quads per group, quads per chunk)
+            (4, 1, 3), (4, 4, 3), (4, 2, 1), (4, 16, 32), (4, 1, 32), (4, 32, 32), (4, 8, 5), (4, 32, 32, 2), (4, 1, 3, 2), (4, 4, 32, 0)]   # a 4th entry = option "cull" (2: packet culling on every bounce, 0: off) # kernel 4 = bf16 matrix-core broad phase, one wave per SIMD: (4, quads per group, quads per chunk)
 
 
 def run_both(rt, oracle, scene, params, W, H, frames=1, rng_state=True, reset_at=None, variant=None):
@@ -17,6 +17,8 @@ def run_both(rt, oracle, scene, params, W, H, frames=1, rng_state=True, reset_at
     ctx.upload_scene(scene)
     if variant is not None and variant[0] == 4:
         ctx.set_option("kernel", 4); ctx.set_option("mf_chunk_quads", variant[2]); ctx.set_option("mf_group_quads", variant[1])
+        if len(variant) > 3:
+            ctx.set_option("cull", variant[3])
     elif variant is not None:
         ctx.set_option("kernel", variant[0]); ctx.set_option("wf_mode", variant[1]); ctx.set_option("wf_rays", variant[2])
         ctx.set_option("wf_chunk", 128)      # small chunks so that even the small test meshes span several work items
