@@ -22,6 +22,7 @@
 // ray block are fetched while the current one is scanned; survivors go to a per-wave LDS queue and from there to the global
 // candidate buffer of the narrow-phase kernel (64-bit counter; what does not fit is tested in place).
 #pragma once
+#include <type_traits>
 #include "rt_mfma.hpp"
 
 #pragma clang fp contract(off)
@@ -30,6 +31,24 @@ namespace rt {
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x8 __attribute__((ext_vector_type(8)));
+
+// max / min over the 32 columns of a wave whose two lane halves hold the same values: four DPP steps inside each row of 16 lanes,
+// then the two rows through scalar registers (ds_bpermute-based shuffles cost an LDS round trip per step: 14 reductions of them
+// were 70 % of the camera-ray bounce once culling had shortened the scan)
+template <bool kMax> __device__ __forceinline__ float half_reduce(float x)
+{
+    auto op = [](float a, float b) { return kMax ? __builtin_fmaxf(a, b) : __builtin_fminf(a, b); };
+    auto dpp = [](float v, auto ctrl) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), decltype(ctrl)::value, 0xf, 0xf, false)); };
+    x = op(x, dpp(x, std::integral_constant<int, 0xB1>{}));      // quad_perm [1,0,3,2]
+    x = op(x, dpp(x, std::integral_constant<int, 0x4E>{}));      // quad_perm [2,3,0,1]
+    x = op(x, dpp(x, std::integral_constant<int, 0x141>{}));     // row_half_mirror
+    x = op(x, dpp(x, std::integral_constant<int, 0x140>{}));     // row_mirror
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), 0));
+    const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), 16));
+    return op(r0, r1);
+}
+__device__ __forceinline__ float half_max(float x) { return half_reduce<true>(x); }
+__device__ __forceinline__ float half_min(float x) { return half_reduce<false>(x); }
 
 constexpr int kSoloSets = 4;                                      // 32-ray sets per wave: 512 rays per block of four waves
 struct SoloCfg {
@@ -177,16 +196,20 @@ scan_solo_kernel(SceneView sc, WaveBuffers wb, MfView mf, uint32_t bounce, uint3
     unsigned long long c_cand_total = 0;
 
     // rays of one block as they sit in the queue: both lane halves hold the same ray
-    float4 nxt_a[S], nxt_b[S];
-    auto fetch_rays = [&](uint32_t base) {
+    // Two ray blocks are in flight ahead of the one being scanned: with culling a camera-ray block is scanned in ~3k cycles, less
+    // than one L2 round trip of its successor's rays
+    float4 nxt_a[S], nxt_b[S], nx2_a[S], nx2_b[S];
+    auto fetch_rays = [&](uint32_t base, float4 (&da)[S], float4 (&db)[S]) {
 #pragma unroll
         for (int s = 0; s < S; ++s) {
             const uint32_t slot = base + (uint32_t)(wave * S + s) * 32u + (uint32_t)col;
-            nxt_a[s] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); nxt_b[s] = nxt_a[s];
-            if (slot < n_rays) { nxt_a[s] = qin.a[slot]; nxt_b[s] = qin.b[slot]; }
+            da[s] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); db[s] = da[s];
+            if (slot < n_rays) { da[s] = qin.a[slot]; db[s] = qin.b[slot]; }
         }
     };
-    fetch_rays(blockIdx.x * Cfg::kRaysPerBlock);
+    const uint32_t kStride = gridDim.x * Cfg::kRaysPerBlock;
+    fetch_rays(blockIdx.x * Cfg::kRaysPerBlock, nxt_a, nxt_b);
+    fetch_rays(blockIdx.x * Cfg::kRaysPerBlock + kStride, nx2_a, nx2_b);
 
     for (uint32_t base = blockIdx.x * Cfg::kRaysPerBlock; base < n_rays; base += gridDim.x * Cfg::kRaysPerBlock) {
         RT_STAMP(ts_iter);
@@ -197,16 +220,18 @@ scan_solo_kernel(SceneView sc, WaveBuffers wb, MfView mf, uint32_t bounce, uint3
             MfRay &r = ray[s];
             r.valid = slot < n_rays;
             r.o = mk(nxt_a[s].x, nxt_a[s].y, nxt_a[s].z); r.d = mk(nxt_a[s].w, nxt_b[s].x, nxt_b[s].y);
-            r.wd = __builtin_sqrtf(dot3(r.d, r.d)) * 1.001f;
-            r.wod = (__builtin_sqrtf(dot3(r.o, r.o)) * 1.001f) * r.wd;
+            r.wd = __builtin_amdgcn_sqrtf(dot3(r.d, r.d)) * 1.001f;               // (1 ulp square roots: these are bounds, inflated by 1.001)
+            r.wod = (__builtin_amdgcn_sqrtf(dot3(r.o, r.o)) * 1.001f) * r.wd;
             const uint32_t dxy = pack_bf16(r.d.x, r.d.y);
             r.dyz = pack_bf16(r.d.y, r.d.z);
             r.dx_hi = dxy << 16;
             const f3 dl = mk(r.d.x - __uint_as_float(dxy << 16), r.d.y - __uint_as_float(dxy & 0xffff0000u), r.d.z - __uint_as_float(r.dyz & 0xffff0000u));
             r.tail = half ? pack_bf16(dl.y, dl.z) : pack_bf16(1.0f, dl.x);
         }
-        // the next block's rays travel while this one is scanned (one wave per SIMD: nothing else would hide the round trip)
-        if (base + gridDim.x * Cfg::kRaysPerBlock < n_rays) fetch_rays(base + gridDim.x * Cfg::kRaysPerBlock);
+        // the next blocks' rays travel while this one is scanned (one wave per SIMD: nothing else would hide the round trip)
+#pragma unroll
+        for (int s = 0; s < S; ++s) { nxt_a[s] = nx2_a[s]; nxt_b[s] = nx2_b[s]; }
+        fetch_rays(base + 2u * kStride, nx2_a, nx2_b);
 
         // ---- packet culling (rt_mfma.hpp, MfCull): which quads of the chunk can this wave's 128 rays not be rejected for?
         uint32_t keep = 0xFFFFFFFFu >> (32u - (q_end - q_begin));              // bit q: quad q of the chunk must be scanned
@@ -218,37 +243,38 @@ scan_solo_kernel(SceneView sc, WaveBuffers wb, MfView mf, uint32_t bounce, uint3
 #pragma unroll
             for (int s = 0; s < S; ++s) {
                 const MfRay &r = ray[s];
-                const float dl = __builtin_sqrtf(dot3(r.d, r.d));
-                dh[s] = mk(r.d.x / dl, r.d.y / dl, r.d.z / dl);
+                // (v_rsq_f32 / v_sqrt_f32 / v_rcp_f32, 1 ulp: these feed bounds that carry 1e-4 relative and 1e-6 absolute slack)
+                const float dd = dot3(r.d, r.d), il = __builtin_amdgcn_rsqf(dd), dl = dd * il;
+                dh[s] = mk(r.d.x * il, r.d.y * il, r.d.z * il);
                 if (r.valid) {
                     usable &= (dl > 0.0f) && (dl < inf) && (fabsf(r.o.x) < 1e18f) && (fabsf(r.o.y) < 1e18f) && (fabsf(r.o.z) < 1e18f);
                     olo = mk(fminf(olo.x, r.o.x), fminf(olo.y, r.o.y), fminf(olo.z, r.o.z)); ohi = mk(fmaxf(ohi.x, r.o.x), fmaxf(ohi.y, r.o.y), fmaxf(ohi.z, r.o.z));
                     dlo = mk(fminf(dlo.x, dh[s].x), fminf(dlo.y, dh[s].y), fminf(dlo.z, dh[s].z)); dhi = mk(fmaxf(dhi.x, dh[s].x), fmaxf(dhi.y, dh[s].y), fmaxf(dhi.z, dh[s].z));
                 }
             }
-            olo = mk(wave_min(olo.x), wave_min(olo.y), wave_min(olo.z)); ohi = mk(wave_max(ohi.x), wave_max(ohi.y), wave_max(ohi.z));
-            dlo = mk(wave_min(dlo.x), wave_min(dlo.y), wave_min(dlo.z)); dhi = mk(wave_max(dhi.x), wave_max(dhi.y), wave_max(dhi.z));
+            olo = mk(half_min(olo.x), half_min(olo.y), half_min(olo.z)); ohi = mk(half_max(ohi.x), half_max(ohi.y), half_max(ohi.z));
+            dlo = mk(half_min(dlo.x), half_min(dlo.y), half_min(dlo.z)); dhi = mk(half_max(dhi.x), half_max(dhi.y), half_max(dhi.z));
             const f3 O = mk(0.5f * olo.x + 0.5f * ohi.x, 0.5f * olo.y + 0.5f * ohi.y, 0.5f * olo.z + 0.5f * ohi.z);
             f3 D = mk(0.5f * dlo.x + 0.5f * dhi.x, 0.5f * dlo.y + 0.5f * dhi.y, 0.5f * dlo.z + 0.5f * dhi.z);
-            const float Dl = __builtin_sqrtf(dot3(D, D));
-            D = mk(D.x / Dl, D.y / Dl, D.z / Dl);
+            const float DD = dot3(D, D), iDl = __builtin_amdgcn_rsqf(DD), Dl = DD * iDl;
+            D = mk(D.x * iDl, D.y * iDl, D.z * iDl);                              // |D| = 1 +- 3e-7: covered by the slack of sigma
             float ro = 0.0f, sigma = 0.0f;
 #pragma unroll
             for (int s = 0; s < S; ++s)
                 if (ray[s].valid) {
                     const f3 eo = ray[s].o - O, ed = dh[s] - D;
-                    ro = fmaxf(ro, __builtin_sqrtf(dot3(eo, eo))); sigma = fmaxf(sigma, __builtin_sqrtf(dot3(ed, ed)));
+                    ro = fmaxf(ro, __builtin_amdgcn_sqrtf(dot3(eo, eo))); sigma = fmaxf(sigma, __builtin_amdgcn_sqrtf(dot3(ed, ed)));
                 }
-            ro = wave_max(ro) * 1.0001f + 1e-30f; sigma = wave_max(sigma) * 1.0001f + 1e-6f;
+            ro = half_max(ro) * 1.0001f + 1e-30f; sigma = half_max(sigma) * 1.0001f + 2e-6f;
             usable = !__any(!usable) && (Dl > 0.25f);                             // (an empty wave has ro = sigma ~ 0 and culls everything it can: it has no rays)
-            const float On = __builtin_sqrtf(dot3(O, O)) * 1.0001f + ro;          // >= |o| of every ray
+            const float On = __builtin_amdgcn_sqrtf(dot3(O, O)) * 1.0001f + ro;   // >= |o| of every ray
             bool skip = false;
             if (usable && (uint32_t)lane < q_end - q_begin) {
                 const MfCull c = lds_cull[lane];
                 const f3 w = mk(c.cx, c.cy, c.cz) - O;
-                const float L = __builtin_sqrtf(dot3(w, w)) * 1.0001f;
+                const float L = __builtin_amdgcn_sqrtf(dot3(w, w)) * 1.0001f;
                 const f3 cr = cross3(w, D);
-                const float crn = __builtin_sqrtf(dot3(cr, cr));
+                const float crn = __builtin_amdgcn_sqrtf(dot3(cr, cr));
                 const float delta = (crn * 0.9999f - L * sigma) - (ro + c.R) - 1e-5f * (L + ro + c.R);      // the lines miss the sphere by at least this
                 // range of D.n^ over the box of the quad's unit normals; |d^.n^ - D.n^| <= sigma
                 const float plo = (fminf(D.x * c.nlx, D.x * c.nhx) + fminf(D.y * c.nly, D.y * c.nhy)) + fminf(D.z * c.nlz, D.z * c.nhz);
