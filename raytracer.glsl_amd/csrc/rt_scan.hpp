@@ -49,6 +49,72 @@ template <bool kMax> __device__ __forceinline__ float half_reduce(float x)
 }
 __device__ __forceinline__ float half_max(float x) { return half_reduce<true>(x); }
 __device__ __forceinline__ float half_min(float x) { return half_reduce<false>(x); }
+// the same over all 64 lanes of a wave (distinct values in both halves)
+template <bool kMax> __device__ __forceinline__ float full_reduce(float x)
+{
+    auto op = [](float a, float b) { return kMax ? __builtin_fmaxf(a, b) : __builtin_fminf(a, b); };
+    auto dpp = [](float v, auto ctrl) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), decltype(ctrl)::value, 0xf, 0xf, false)); };
+    x = op(x, dpp(x, std::integral_constant<int, 0xB1>{}));
+    x = op(x, dpp(x, std::integral_constant<int, 0x4E>{}));
+    x = op(x, dpp(x, std::integral_constant<int, 0x141>{}));
+    x = op(x, dpp(x, std::integral_constant<int, 0x140>{}));
+    auto rl = [&](int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), l)); };
+    return op(op(rl(0), rl(16)), op(rl(32), rl(48)));
+}
+
+// ---- packet bounds: for every granule of 128 consecutive rays of a queue (= the rays one scan wave handles per trip) an origin
+// sphere (O, ro), a direction cone (unit D, sigma = max |d^ - D|) and On >= max |o|.  One wave per granule, two rays per lane.
+// record: [O.xyz, ro] [D.xyz, sigma] [On, usable, 0, 0]; usable = 0 when a ray has a non-finite origin or a direction that cannot
+// be normalised, or when the directions spread too widely to have an axis: the scan then culls nothing for that granule.
+__global__ void __launch_bounds__(256) packet_bounds_kernel(WaveBuffers wb, uint32_t bounce)
+{
+    const uint32_t n_rays = wb.counts[bounce];
+    const RayQueue qin = (bounce & 1u) ? wb.q[1] : wb.q[0];
+    const uint32_t lane = threadIdx.x & 63u, n_gran = (n_rays + 127u) / 128u;
+    const float inf = __builtin_inff();
+    for (uint32_t g = blockIdx.x * 4u + (threadIdx.x >> 6); g < n_gran; g += gridDim.x * 4u) {
+        f3 o[2], dh[2]; bool valid[2]; bool usable = true;
+        f3 olo = mk(inf, inf, inf), ohi = mk(-inf, -inf, -inf), dlo = olo, dhi = ohi;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const uint32_t slot = g * 128u + (uint32_t)k * 64u + lane;
+            valid[k] = slot < n_rays;
+            o[k] = mk(0.0f, 0.0f, 0.0f); dh[k] = o[k];
+            if (valid[k]) {
+                const float4 a = qin.a[slot], b = qin.b[slot];
+                o[k] = mk(a.x, a.y, a.z);
+                const f3 d = mk(a.w, b.x, b.y);
+                // (v_rsq_f32, 1 ulp: this feeds bounds that carry 1e-4 relative and 1e-6 absolute slack)
+                const float dd = dot3(d, d), il = __builtin_amdgcn_rsqf(dd), dl = dd * il;
+                dh[k] = mk(d.x * il, d.y * il, d.z * il);
+                usable &= (dl > 0.0f) && (dl < inf) && (fabsf(o[k].x) < 1e18f) && (fabsf(o[k].y) < 1e18f) && (fabsf(o[k].z) < 1e18f);
+                olo = mk(fminf(olo.x, o[k].x), fminf(olo.y, o[k].y), fminf(olo.z, o[k].z)); ohi = mk(fmaxf(ohi.x, o[k].x), fmaxf(ohi.y, o[k].y), fmaxf(ohi.z, o[k].z));
+                dlo = mk(fminf(dlo.x, dh[k].x), fminf(dlo.y, dh[k].y), fminf(dlo.z, dh[k].z)); dhi = mk(fmaxf(dhi.x, dh[k].x), fmaxf(dhi.y, dh[k].y), fmaxf(dhi.z, dh[k].z));
+            }
+        }
+        olo = mk(full_reduce<false>(olo.x), full_reduce<false>(olo.y), full_reduce<false>(olo.z)); ohi = mk(full_reduce<true>(ohi.x), full_reduce<true>(ohi.y), full_reduce<true>(ohi.z));
+        dlo = mk(full_reduce<false>(dlo.x), full_reduce<false>(dlo.y), full_reduce<false>(dlo.z)); dhi = mk(full_reduce<true>(dhi.x), full_reduce<true>(dhi.y), full_reduce<true>(dhi.z));
+        const f3 O = mk(0.5f * olo.x + 0.5f * ohi.x, 0.5f * olo.y + 0.5f * ohi.y, 0.5f * olo.z + 0.5f * ohi.z);
+        f3 D = mk(0.5f * dlo.x + 0.5f * dhi.x, 0.5f * dlo.y + 0.5f * dhi.y, 0.5f * dlo.z + 0.5f * dhi.z);
+        const float DD = dot3(D, D), iDl = __builtin_amdgcn_rsqf(DD), Dl = DD * iDl;
+        D = mk(D.x * iDl, D.y * iDl, D.z * iDl);                              // |D| = 1 +- 3e-7: covered by the slack of sigma
+        float ro = 0.0f, sigma = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+            if (valid[k]) {
+                const f3 eo = o[k] - O, ed = dh[k] - D;
+                ro = fmaxf(ro, __builtin_amdgcn_sqrtf(dot3(eo, eo))); sigma = fmaxf(sigma, __builtin_amdgcn_sqrtf(dot3(ed, ed)));
+            }
+        ro = full_reduce<true>(ro) * 1.0001f + 1e-30f; sigma = full_reduce<true>(sigma) * 1.0001f + 2e-6f;
+        usable = !__any(!usable) && (Dl > 0.25f);
+        const float On = __builtin_amdgcn_sqrtf(dot3(O, O)) * 1.0001f + ro;
+        if (lane == 0u) {
+            wb.packets[3 * (size_t)g + 0] = make_float4(O.x, O.y, O.z, ro);
+            wb.packets[3 * (size_t)g + 1] = make_float4(D.x, D.y, D.z, sigma);
+            wb.packets[3 * (size_t)g + 2] = make_float4(On, usable ? 1.0f : 0.0f, 0.0f, 0.0f);
+        }
+    }
+}
 
 constexpr int kSoloSets = 4;                                      // 32-ray sets per wave: 512 rays per block of four waves
 struct SoloCfg {
@@ -213,6 +279,46 @@ scan_solo_kernel(SceneView sc, WaveBuffers wb, MfView mf, uint32_t bounce, uint3
 
     for (uint32_t base = blockIdx.x * Cfg::kRaysPerBlock; base < n_rays; base += gridDim.x * Cfg::kRaysPerBlock) {
         RT_STAMP(ts_iter);
+        const uint32_t wave_slot0 = base + (uint32_t)(wave * S) * 32u;
+        // ---- packet culling (rt_mfma.hpp, MfCull): which quads of the chunk can this wave's 128 rays not be rejected for?  The bounds
+        // of the wave's rays come from packet_bounds_kernel (one record per 128 rays; read through the scalar cache).
+        uint32_t keep = 0xFFFFFFFFu >> (32u - (q_end - q_begin));              // bit q: quad q of the chunk must be scanned
+        if (cull) {
+            typedef const float __attribute__((address_space(4))) *ConstRec;
+            const uint32_t gran = __builtin_amdgcn_readfirstlane((base >> 7) + (uint32_t)wave);
+            const ConstRec pk = (ConstRec)(uintptr_t)(wb.packets + 3 * (size_t)gran);
+            const f3 O = mk(pk[0], pk[1], pk[2]), D = mk(pk[4], pk[5], pk[6]);
+            const float ro = pk[3], sigma = pk[7], On = pk[8];
+            const bool usable = pk[9] != 0.0f;
+            bool skip = false;
+            if (usable && (uint32_t)lane < q_end - q_begin) {
+                const MfCull c = lds_cull[lane];
+                const f3 w = mk(c.cx, c.cy, c.cz) - O;
+                const float L = __builtin_amdgcn_sqrtf(dot3(w, w)) * 1.0001f;
+                const f3 cr = cross3(w, D);
+                const float crn = __builtin_amdgcn_sqrtf(dot3(cr, cr));
+                const float delta = (crn * 0.9999f - L * sigma) - (ro + c.R) - 1e-5f * (L + ro + c.R);      // the lines miss the sphere by at least this
+                // range of D.n^ over the box of the quad's unit normals; |d^.n^ - D.n^| <= sigma
+                const float plo = (fminf(D.x * c.nlx, D.x * c.nhx) + fminf(D.y * c.nly, D.y * c.nhy)) + fminf(D.z * c.nlz, D.z * c.nhz);
+                const float phi = (fmaxf(D.x * c.nlx, D.x * c.nhx) + fmaxf(D.y * c.nly, D.y * c.nhy)) + fmaxf(D.z * c.nlz, D.z * c.nhz);
+                const float cmin = ((plo > 0.0f) ? plo : ((phi < 0.0f) ? -phi : -1.0f)) - sigma - 1e-5f;
+                const float lhs = (c.Nmin * cmin) * fminf(0.3333f, delta * c.shape) * 0.99f;
+                const float rhs = 9.5367431640625e-07f * __builtin_fmaf(c.E, On, c.Pw) * 1.01f;      // 2^-20 (E |o| + Pw): the reference's own rounding (mf_margin)
+                skip = (delta > 0.0f) && (cmin > 0.0f) && (c.Nmin > 0.0f) && (lhs > 0.0f) && (lhs >= rhs);    // any NaN: false
+            }
+            keep &= ~(uint32_t)__builtin_amdgcn_ballot_w64(skip);
+        }
+        if (kCount && lane == 0) {
+            const uint32_t culled = (uint32_t)__builtin_popcount(~keep & (0xFFFFFFFFu >> (32u - (q_end - q_begin))));
+            const uint32_t rays_here = wave_slot0 < n_rays ? min(128u, n_rays - wave_slot0) : 0u;
+            c_culled += (unsigned long long)culled * kMfQuadTris * rays_here;
+        }
+        if (keep == 0u) {                                      // nothing of this chunk can be hit by this wave's rays: next ray block
+#pragma unroll
+            for (int s = 0; s < S; ++s) { nxt_a[s] = nx2_a[s]; nxt_b[s] = nx2_b[s]; }
+            fetch_rays(base + 2u * kStride, nx2_a, nx2_b);
+            continue;
+        }
         MfRay ray[S];
 #pragma unroll
         for (int s = 0; s < S; ++s) {
@@ -233,61 +339,7 @@ scan_solo_kernel(SceneView sc, WaveBuffers wb, MfView mf, uint32_t bounce, uint3
         for (int s = 0; s < S; ++s) { nxt_a[s] = nx2_a[s]; nxt_b[s] = nx2_b[s]; }
         fetch_rays(base + 2u * kStride, nx2_a, nx2_b);
 
-        // ---- packet culling (rt_mfma.hpp, MfCull): which quads of the chunk can this wave's 128 rays not be rejected for?
-        uint32_t keep = 0xFFFFFFFFu >> (32u - (q_end - q_begin));              // bit q: quad q of the chunk must be scanned
-        if (cull) {
-            const float inf = __builtin_inff();
-            f3 olo = mk(inf, inf, inf), ohi = mk(-inf, -inf, -inf), dlo = olo, dhi = ohi;
-            f3 dh[S];
-            bool usable = true;                                                   // every valid ray has a finite origin and a normalisable direction
-#pragma unroll
-            for (int s = 0; s < S; ++s) {
-                const MfRay &r = ray[s];
-                // (v_rsq_f32 / v_sqrt_f32 / v_rcp_f32, 1 ulp: these feed bounds that carry 1e-4 relative and 1e-6 absolute slack)
-                const float dd = dot3(r.d, r.d), il = __builtin_amdgcn_rsqf(dd), dl = dd * il;
-                dh[s] = mk(r.d.x * il, r.d.y * il, r.d.z * il);
-                if (r.valid) {
-                    usable &= (dl > 0.0f) && (dl < inf) && (fabsf(r.o.x) < 1e18f) && (fabsf(r.o.y) < 1e18f) && (fabsf(r.o.z) < 1e18f);
-                    olo = mk(fminf(olo.x, r.o.x), fminf(olo.y, r.o.y), fminf(olo.z, r.o.z)); ohi = mk(fmaxf(ohi.x, r.o.x), fmaxf(ohi.y, r.o.y), fmaxf(ohi.z, r.o.z));
-                    dlo = mk(fminf(dlo.x, dh[s].x), fminf(dlo.y, dh[s].y), fminf(dlo.z, dh[s].z)); dhi = mk(fmaxf(dhi.x, dh[s].x), fmaxf(dhi.y, dh[s].y), fmaxf(dhi.z, dh[s].z));
-                }
-            }
-            olo = mk(half_min(olo.x), half_min(olo.y), half_min(olo.z)); ohi = mk(half_max(ohi.x), half_max(ohi.y), half_max(ohi.z));
-            dlo = mk(half_min(dlo.x), half_min(dlo.y), half_min(dlo.z)); dhi = mk(half_max(dhi.x), half_max(dhi.y), half_max(dhi.z));
-            const f3 O = mk(0.5f * olo.x + 0.5f * ohi.x, 0.5f * olo.y + 0.5f * ohi.y, 0.5f * olo.z + 0.5f * ohi.z);
-            f3 D = mk(0.5f * dlo.x + 0.5f * dhi.x, 0.5f * dlo.y + 0.5f * dhi.y, 0.5f * dlo.z + 0.5f * dhi.z);
-            const float DD = dot3(D, D), iDl = __builtin_amdgcn_rsqf(DD), Dl = DD * iDl;
-            D = mk(D.x * iDl, D.y * iDl, D.z * iDl);                              // |D| = 1 +- 3e-7: covered by the slack of sigma
-            float ro = 0.0f, sigma = 0.0f;
-#pragma unroll
-            for (int s = 0; s < S; ++s)
-                if (ray[s].valid) {
-                    const f3 eo = ray[s].o - O, ed = dh[s] - D;
-                    ro = fmaxf(ro, __builtin_amdgcn_sqrtf(dot3(eo, eo))); sigma = fmaxf(sigma, __builtin_amdgcn_sqrtf(dot3(ed, ed)));
-                }
-            ro = half_max(ro) * 1.0001f + 1e-30f; sigma = half_max(sigma) * 1.0001f + 2e-6f;
-            usable = !__any(!usable) && (Dl > 0.25f);                             // (an empty wave has ro = sigma ~ 0 and culls everything it can: it has no rays)
-            const float On = __builtin_amdgcn_sqrtf(dot3(O, O)) * 1.0001f + ro;   // >= |o| of every ray
-            bool skip = false;
-            if (usable && (uint32_t)lane < q_end - q_begin) {
-                const MfCull c = lds_cull[lane];
-                const f3 w = mk(c.cx, c.cy, c.cz) - O;
-                const float L = __builtin_amdgcn_sqrtf(dot3(w, w)) * 1.0001f;
-                const f3 cr = cross3(w, D);
-                const float crn = __builtin_amdgcn_sqrtf(dot3(cr, cr));
-                const float delta = (crn * 0.9999f - L * sigma) - (ro + c.R) - 1e-5f * (L + ro + c.R);      // the lines miss the sphere by at least this
-                // range of D.n^ over the box of the quad's unit normals; |d^.n^ - D.n^| <= sigma
-                const float plo = (fminf(D.x * c.nlx, D.x * c.nhx) + fminf(D.y * c.nly, D.y * c.nhy)) + fminf(D.z * c.nlz, D.z * c.nhz);
-                const float phi = (fmaxf(D.x * c.nlx, D.x * c.nhx) + fmaxf(D.y * c.nly, D.y * c.nhy)) + fmaxf(D.z * c.nlz, D.z * c.nhz);
-                const float cmin = ((plo > 0.0f) ? plo : ((phi < 0.0f) ? -phi : -1.0f)) - sigma - 1e-5f;
-                const float lhs = (c.Nmin * cmin) * fminf(0.3333f, delta * c.shape) * 0.99f;
-                const float rhs = 9.5367431640625e-07f * __builtin_fmaf(c.E, On, c.Pw) * 1.01f;      // 2^-20 (E |o| + Pw): the reference's own rounding (mf_margin)
-                skip = (delta > 0.0f) && (cmin > 0.0f) && (c.Nmin > 0.0f) && (lhs > 0.0f) && (lhs >= rhs);    // any NaN: false
-            }
-            keep &= ~(uint32_t)__builtin_amdgcn_ballot_w64(skip);
-        }
         uint32_t qn = 0, n_total = 0;                            // wave-uniform
-        const uint32_t wave_slot0 = base + (uint32_t)(wave * S) * 32u;
         auto flush = [&]() {
             // the (queue slot, storage position) pairs are appended to the wave's region, coalesced, fire and forget (the narrow
             // phase maps storage position -> visit index); what does not fit gets its exact test right here, so the result never
@@ -420,11 +472,6 @@ scan_solo_kernel(SceneView sc, WaveBuffers wb, MfView mf, uint32_t bounce, uint3
         tt_iters++;
 #endif
         c_cand_total += (lane == 0) ? n_total : 0u;
-        if (kCount && lane == 0) {
-            const uint32_t culled = (uint32_t)__builtin_popcount(~keep & (0xFFFFFFFFu >> (32u - (q_end - q_begin))));
-            const uint32_t rays_here = wave_slot0 < n_rays ? min(128u, n_rays - wave_slot0) : 0u;
-            c_culled += (unsigned long long)culled * kMfQuadTris * rays_here;
-        }
     }
 #ifdef RT_SOLO_STAMPS
     if (lane == 0 && mf.dbg_log) {

@@ -48,6 +48,7 @@ struct WaveBuffers {
                                   // one region of `cand_region` pairs per wave of the scan launch
     uint32_t *cand_counts;        // kernel 4: pairs stored in each region by the scan launch of the current bounce
     uint32_t cand_region;         // capacity of one region (pairs); what does not fit is tested in place by the scan
+    float4 *packets;              // kernel 4 packet culling: three float4 per granule of 128 rays of the queue being scanned (rt_scan.hpp)
     uint32_t *cand_peak;          // max over the frame's scan waves of the pairs a wave wanted to append (host: sizes the regions)
 };
 

@@ -189,6 +189,7 @@ struct rtgl_context {
     // kernel 4 candidate buffer: one region per wave of a scan launch.  Sized from what the scene needs, not from the image: it starts
     // at 1.5 pairs per ray and grows to 1.25 x the fullest region any finished frame reported (pairs that do not fit are tested
     // in place by the scan, so every size is correct; a too small one is only slower)
+    float4 *d_packets = nullptr; uint32_t packets_capacity = 0;
     uint2 *d_cand = nullptr; uint32_t cand_regions = 0, cand_region_pairs = 0, cand_region_target = 0; bool cand_fixed = false;
     bool solo_attr_set = false;              // hipFuncAttributeMaxDynamicSharedMemorySize is per device: raised once per context (= per device binding)
     bool kernel_explicit = false;            // "kernel" was set through rtgl_set_option or RTGL_AMD_KERNEL
@@ -298,7 +299,7 @@ extern "C" void rtgl_destroy(rtgl_context *ctx)
 #endif
     void *ptrs[] = { ctx->d_spheres, ctx->d_materials, ctx->d_vertices, ctx->d_sphere_visits, ctx->d_edges, ctx->d_planes,
                      ctx->d_env, ctx->d_image_own, ctx->d_rng, ctx->d_counters, ctx->d_u8, ctx->d_group_bounds, ctx->d_wave, ctx->d_counts, ctx->d_mf_groups, ctx->d_mf_A, ctx->d_mf_order,
-                     ctx->d_dbg_log, ctx->d_cand, ctx->d_mf_cull };
+                     ctx->d_dbg_log, ctx->d_cand, ctx->d_mf_cull, ctx->d_packets };
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (hipEvent_t e : ctx->kev) (void)hipEventDestroy(e);
     if (ctx->h_counts) (void)hipHostFree(ctx->h_counts);
@@ -630,6 +631,12 @@ static int ensure_wave_buffers(rtgl_context *ctx, uint32_t n0, uint32_t max_boun
             ctx->cand_regions = need_regions; ctx->cand_region_pairs = ctx->cand_region_target;
             HIPCHK(ctx, hipMalloc((void **)&ctx->d_cand, ((size_t)need_regions * ctx->cand_region_pairs) * sizeof(uint2) + (size_t)need_regions * sizeof(uint32_t) + 256));
         }
+        if (ctx->packets_capacity < n0) {                      // packet-culling records: 48 B per 128 rays
+            if (ctx->d_packets) { HIPCHK(ctx, hipFree(ctx->d_packets)); ctx->d_packets = nullptr; }
+            HIPCHK(ctx, hipMalloc((void **)&ctx->d_packets, ((size_t)n0 / 128 + 2) * 3 * sizeof(float4)));
+            ctx->packets_capacity = n0;
+        }
+        ctx->wb.packets = ctx->d_packets;
         ctx->wb.cand = ctx->d_cand;
         ctx->wb.cand_counts = reinterpret_cast<uint32_t *>(ctx->d_cand + (size_t)ctx->cand_regions * ctx->cand_region_pairs);
         ctx->wb.cand_region = ctx->cand_region_pairs;
@@ -736,6 +743,10 @@ static int launch_intersect_solo(rtgl_context *ctx, const SceneView &sc, uint32_
     dim3 grid(blocks_x, chunks);
     // packet culling pays where the 128 rays of a wave are coherent: the camera rays (option "cull": 0 never, 1 bounce 0 (default), 2 every bounce)
     const int cull = ctx->opt_cull == 2 || (ctx->opt_cull == 1 && bounce == 0);
+    if (cull) {
+        const uint32_t gran = (est + 127u) / 128u;
+        hipLaunchKernelGGL(packet_bounds_kernel, dim3(std::max(1u, std::min((gran + 3u) / 4u, 4096u))), dim3(256), 0, ctx->stream, ctx->wb, bounce);
+    }
     if (ctx->opt_counters)
         hipLaunchKernelGGL((scan_solo_kernel<true>), grid, dim3(256), lds, ctx->stream, sc, ctx->wb, mf, bounce, chunk_quads, ctx->d_counters, ctx->opt_debug_skip_exact, cull);
     else
