@@ -7,7 +7,7 @@ sc = rt.scenes
 cfg = sc.CONFIGS["C2"]; W, H = cfg["width"], cfg["height"]; scene = cfg["scene"]()
 base = cfg["params"]()
 t1 = None
-STRIP = int(os.environ.get("STRIP", "16"))
+STRIP = int(os.environ.get("STRIP", "8"))
 ALL = os.environ.get("ALL_RANKS", "0") == "1"
 for world in (1, 2, 4, 8):
     for rank in (range(world) if ALL and world == 8 else sorted({0, world - 1})):
