@@ -718,10 +718,17 @@ static int launch_intersect_solo(rtgl_context *ctx, const SceneView &sc, uint32_
 {
     const uint32_t gq = ctx->mf_group_quads, n_quads = ctx->n_mf_groups * gq;
     const uint32_t real_quads = std::min(n_quads, (ctx->n_tri_visits + (uint32_t)kMfQuadTris - 1) / (uint32_t)kMfQuadTris);
-    const uint32_t chunk_quads = std::min((uint32_t)ctx->opt_mf_chunk_quads, std::max(real_quads, 1u));
-    const uint32_t chunks = solo_chunks(ctx);
     using Cfg = SoloCfg;
     const uint32_t est = estimate_rays(ctx, n0, bounce), blocks_x_all = (est + Cfg::kRaysPerBlock - 1u) / Cfg::kRaysPerBlock;
+    // A launch has (ray blocks x chunks) work items for one block per CU.  Late bounces (and every bounce of a rank that owns an
+    // eighth of the image) have few ray blocks: cut the triangle range finer, down to 4 quads per chunk, until there are two items
+    // per CU (each item pays its ray and group set-up again, ~20 % at 8 quads, so only as far as needed; never more chunks than CUs:
+    // the candidate regions are one per wave of a full-width launch)
+    uint32_t chunk_quads = std::min((uint32_t)ctx->opt_mf_chunk_quads, std::max(real_quads, 1u));
+    while (chunk_quads > 4u && (uint64_t)blocks_x_all * ((real_quads + chunk_quads - 1) / chunk_quads) < 2ull * (uint32_t)ctx->n_cus
+           && (real_quads + chunk_quads / 2 - 1) / (chunk_quads / 2) <= (uint32_t)ctx->n_cus)
+        chunk_quads /= 2u;
+    const uint32_t chunks = (real_quads + chunk_quads - 1) / chunk_quads;
     // one block per CU in total: with more, the surplus runs as a second, mostly empty round
     const uint32_t blocks_x = std::max(1u, std::min(blocks_x_all, (uint32_t)ctx->n_cus / chunks));
     const size_t lds = std::max<size_t>(((size_t)chunk_quads * kMfQuadTiles + 2) * 1024 + (size_t)chunk_quads * sizeof(MfCull), 96 * 1024);   // + the two rows read a trip ahead behind the last tile; > half of the CU's LDS with the static queue: one block per CU
