@@ -86,7 +86,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sync-each-frame", action="store_true", help="diagnostic: host waits for every frame")
     ap.add_argument("--no-kernel-timing", action="store_true", help="diagnostic: no HIP events around the scan launches")
-    ap.add_argument("--cpu-rows", type=int, default=256)
+    ap.add_argument("--cpu-rows", type=int, default=1080, help="rows of the frame the CPU baseline renders (8-row strips, uniformly strided): 1080 = the whole C2 frame, ~10 s on 16 threads")
     args = ap.parse_args()
 
     import torch

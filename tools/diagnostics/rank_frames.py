@@ -7,7 +7,7 @@ sc = rt.scenes
 world = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 rank = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 n = int(sys.argv[3]) if len(sys.argv) > 3 else 50
-cfg = sc.CONFIGS["C2"]; W, H = cfg["width"], cfg["height"]; scene = cfg["scene"](); base = cfg["params"]()
+cfg = sc.CONFIGS[os.environ.get("CONFIG", "C2")]; W, H = cfg["width"], cfg["height"]; scene = cfg["scene"](); base = cfg["params"]()
 ctx = rt.host.Context(W, H, device=0, rank=rank, world=world, strip_rows=8)
 ctx.upload_scene(scene)
 g = sc.GlibcRand(0); ps = [base.replace(frames=f, random=g.rand()) for f in range(1, n + 6)]
