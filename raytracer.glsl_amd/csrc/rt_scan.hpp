@@ -118,9 +118,9 @@ __global__ void __launch_bounds__(256) packet_bounds_kernel(WaveBuffers wb, uint
 
 constexpr int kSoloSets = 4;                                      // 32-ray sets per wave: 512 rays per block of four waves
 struct SoloCfg {
-    static constexpr uint32_t kStepMax = (uint32_t)kSoloSets * 5u * 64u;     // one examined tile adds at most S x 5 triangles x 64 lanes entries
+    static constexpr uint32_t kStepMax = 2u * 64u;                    // a trip examines two tiles; a tile adds at most one entry per lane
     static constexpr uint32_t kDrain = 192u;                          // the queue is handed over once it holds this many
-    static constexpr uint32_t kQueue = kStepMax + kDrain;             // entries per wave
+    static constexpr uint32_t kQueue = kStepMax + kDrain + 1u;        // entries per wave (+ one scratch entry lanes without a survivor write to)
     static constexpr uint32_t kRaysPerBlock = 4u * (uint32_t)kSoloSets * 32u;
 };
 
@@ -198,6 +198,19 @@ struct SoloCfg {
                  : "{v[192:207]}"(Y0), "{v[208:223]}"(Y1), "{v[224:239]}"(Y2), "{v[240:255]}"(Y3), [t0] "v"(th0), [t1] "v"(th1), [t2] "v"(th2), [t3] "v"(th3) \
                  : RT_K_CLOBBERS)
 
+// the 20-bit survivor mask of a lane from a minima block set: bit 5 s + u = !(minimum u of ray set s <= threshold s).  Built with the
+// carry chain (v_cmp -> vcc, v_addc_co: mask = 2 mask + vcc), highest bit first: 40 vector instructions, no scalar ones.
+#define RT_MASK_BIT(ML, U, TH) "v_cmp_nle_f32_e32 vcc, v[" #ML "+" #U "], " TH "\n\tv_addc_co_u32_e32 %[m], vcc, %[m], %[m], vcc\n\t"
+#define RT_MASK_SET(ML, TH) RT_MASK_BIT(ML, 4, TH) RT_MASK_BIT(ML, 3, TH) RT_MASK_BIT(ML, 2, TH) RT_MASK_BIT(ML, 1, TH) RT_MASK_BIT(ML, 0, TH)
+#define RT_MASK_A(MASK) \
+    asm volatile("v_mov_b32_e32 %[m], 0\n\t" RT_MASK_SET(120, "%[t3]") RT_MASK_SET(112, "%[t2]") RT_MASK_SET(104, "%[t1]") RT_MASK_SET(96, "%[t0]") \
+                 : [m] "=&v"(MASK) : "{v[96:103]}"(MA0), "{v[104:111]}"(MA1), "{v[112:119]}"(MA2), "{v[120:127]}"(MA3), \
+                   [t0] "v"(th0), [t1] "v"(th1), [t2] "v"(th2), [t3] "v"(th3) : "vcc")
+#define RT_MASK_B(MASK) \
+    asm volatile("v_mov_b32_e32 %[m], 0\n\t" RT_MASK_SET(88, "%[t3]") RT_MASK_SET(80, "%[t2]") RT_MASK_SET(72, "%[t1]") RT_MASK_SET(64, "%[t0]") \
+                 : [m] "=&v"(MASK) : "{v[64:71]}"(MB0), "{v[72:79]}"(MB1), "{v[80:87]}"(MB2), "{v[88:95]}"(MB3), \
+                   [t0] "v"(th0), [t1] "v"(th1), [t2] "v"(th2), [t3] "v"(th3) : "vcc")
+
 // diagnostics build (-DRT_SOLO_STAMPS): s_memtime stamps around the phases of a wave's life, summed into mf.dbg_log
 #ifdef RT_SOLO_STAMPS
 #define RT_STAMP(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
@@ -214,7 +227,7 @@ scan_solo_kernel(SceneView sc, WaveBuffers wb, MfView mf, uint32_t bounce, uint3
     using Cfg = SoloCfg;
     constexpr int S = kSoloSets;
     extern __shared__ uint4 lds_tiles[];                      // the chunk's A tiles, [quad][tile][panel][row]
-    __shared__ uint32_t lds_queue[4 * Cfg::kQueue];          // per-wave survivor queue, entry = (ray in wave) << 16 | triangle offset in chunk
+    __shared__ uint2 lds_queue[4 * Cfg::kQueue];             // per-wave survivor queue, entry = (lane | tile in chunk << 8, 20-bit mask: bit 5 s + u = triangle u of the lane's half survived for ray set s)
     RT_STAMP(ts_begin);
 #ifdef RT_SOLO_STAMPS
     unsigned long long tt_stage = 0, tt_rays = 0, tt_group = 0, tt_steady = 0, tt_park = 0, tt_flush = 0, tt_iters = 0;
@@ -255,11 +268,11 @@ scan_solo_kernel(SceneView sc, WaveBuffers wb, MfView mf, uint32_t bounce, uint3
     unsigned long long c_culled = 0;
     RT_STAMP(ts_staged);
     RT_STAMP_ADD(tt_stage, ts_begin, ts_staged);
-    uint32_t *queue = lds_queue + wave * Cfg::kQueue;
+    uint2 *queue = lds_queue + wave * Cfg::kQueue;
+    unsigned long long c_cand_lane = 0;                        // kCount: surviving pairs this lane handed over
     typedef const float __attribute__((address_space(4))) *ConstFloats;       // group records: uniform index => s_load
     const ConstFloats groups_k = (ConstFloats)(uintptr_t)mf.groups;
     const uint32_t l_lane = (uint32_t)half * 32u + (uint32_t)col;              // this lane's row inside a tile (uint4 index)
-    unsigned long long c_cand_total = 0;
 
     // rays of one block as they sit in the queue: both lane halves hold the same ray
     // Two ray blocks are in flight ahead of the one being scanned: with culling a camera-ray block is scanned in ~3k cycles, less
@@ -339,21 +352,29 @@ scan_solo_kernel(SceneView sc, WaveBuffers wb, MfView mf, uint32_t bounce, uint3
         for (int s = 0; s < S; ++s) { nxt_a[s] = nx2_a[s]; nxt_b[s] = nx2_b[s]; }
         fetch_rays(base + 2u * kStride, nx2_a, nx2_b);
 
-        uint32_t qn = 0, n_total = 0;                            // wave-uniform
+        uint32_t qn = 0;                                        // wave-uniform
         auto flush = [&]() {
-            // the (queue slot, storage position) pairs are appended to the wave's region, coalesced, fire and forget (the narrow
-            // phase maps storage position -> visit index); what does not fit gets its exact test right here, so the result never
-            // depends on the buffer size.  `appended` is 64 bits wide: a degenerate scene (NaN bounds: every pair survives) can
-            // exceed 2^32 pairs per wave.
-            for (uint32_t i = (uint32_t)lane; i < qn; i += 64u) {
-                const uint32_t e = queue[i], pos = v_chunk_begin + (e & 0xffffu);
-                const bool real = pos < v_chunk_end && debug_skip_exact == 0;
-                const uint32_t slot = wave_slot0 + (e >> 16);
-                if (appended + i < (unsigned long long)wb.cand_region) cand[appended + i] = make_uint2(real ? slot : 0xFFFFFFFFu, pos);
-                else if (real) exact_and_merge(sc, qin, best, slot, mf.order[pos]);
+            // Every queue entry becomes four records (queue slot of the ray, storage position of the lane's first triangle << 5 | the
+            // 5-bit survivor mask of that ray set), appended to the wave's region coalesced, fire and forget; the narrow phase expands
+            // the masks and maps storage position -> visit index.  What does not fit gets its exact tests right here, so the result
+            // never depends on the buffer size.  `appended` is 64 bits wide: a degenerate scene (NaN bounds: every pair survives) can
+            // exceed 2^32 records per wave.
+            for (uint32_t j = (uint32_t)lane; j < 4u * qn; j += 64u) {      // record j = (entry j / 4, ray set j % 4)
+                const uint2 e = queue[j >> 2];
+                const uint32_t rs = j & 3u, ln = e.x & 63u, pos5 = v_chunk_begin + (e.x >> 8) * kMfTileTris + 5u * (ln >> 5);
+                if (kCount && rs == 0u) c_cand_lane += (unsigned long long)__popc(e.y);
+                uint32_t um = debug_skip_exact == 0 ? (e.y >> (5u * rs)) & 31u : 0u;
+                const uint32_t slot = wave_slot0 + rs * 32u + (ln & 31u);
+                const unsigned long long at = appended + (unsigned long long)j;
+                if (at < (unsigned long long)wb.cand_region) cand[at] = make_uint2(slot, (pos5 << 5) | um);
+                else
+                    while (um) {
+                        const uint32_t pos = pos5 + (uint32_t)__builtin_ctz(um);
+                        um &= um - 1u;
+                        if (pos < v_chunk_end) exact_and_merge(sc, qin, best, slot, mf.order[pos]);
+                    }
             }
-            appended += qn;
-            n_total += qn;
+            appended += 4ull * qn;
             qn = 0;
         };
 
@@ -362,35 +383,21 @@ scan_solo_kernel(SceneView sc, WaveBuffers wb, MfView mf, uint32_t bounce, uint3
         f32x16 X0, X1, X2, X3, Y0, Y1, Y2, Y3;
         f32x8 MA0, MA1, MA2, MA3, MB0, MB1, MB2, MB3;            // [0..4]: minima of the five triangles of the lane's half
         unsigned long long any_a, any_b;                        // lanes with a survivor in the tile examined into MA / MB
-        // rare path: some lane has a survivor in `tile` (index inside the chunk) -> per (ray set, triangle) ballots, survivors
-        // into the wave's LDS queue.  A finite threshold means finite operands and edge values below 2^7 * 1e30 in magnitude,
-        // hence finite minima: max-of-minima > threshold is then exactly "some triangle of this lane survives"; a NaN threshold
-        // passes all.
-        auto park_set = [&](uint32_t tile, int s, const f32x8 &mq, float th) {
-#pragma unroll
-            for (int u = 0; u < 5; ++u) {
-                const unsigned long long m = __builtin_amdgcn_ballot_w64(!(mq[u] <= th));
-                if (m) {                                                        // wave-uniform
-                    if ((m >> lane) & 1ull) {
-                        const uint32_t v_off = tile * kMfTileTris + 5u * (uint32_t)half + (uint32_t)u;
-                        queue[qn + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = ((uint32_t)(s * 32 + col) << 16) | v_off;
-                    }
-                    qn += (uint32_t)__popcll(m);
-                }
-            }
-        };
-        // (slot 5 of a minima block is the maximum of the five: the per-set "anything here?" is re-derived from it instead of from the
-        // stage's scalar masks, which then never leave their registers)
-        auto park = [&](uint32_t tile, const f32x8 &M0, const f32x8 &M1, const f32x8 &M2, const f32x8 &M3) {
-            RT_STAMP(ts_p0);
-            if (__builtin_amdgcn_ballot_w64(!(M0[5] <= th0))) park_set(tile, 0, M0, th0);
-            if (__builtin_amdgcn_ballot_w64(!(M1[5] <= th1))) park_set(tile, 1, M1, th1);
-            if (__builtin_amdgcn_ballot_w64(!(M2[5] <= th2))) park_set(tile, 2, M2, th2);
-            if (__builtin_amdgcn_ballot_w64(!(M3[5] <= th3))) park_set(tile, 3, M3, th3);
+        // rare path: some lane has a survivor in `tile` (index inside the chunk).  Branch-free: every lane builds the 20-bit mask of
+        // its surviving (ray set, triangle) pairs from the minima the stage left behind, lanes with a non-empty mask append ONE entry
+        // to the wave's LDS queue (the others write to a scratch entry).  (The first form of this path tested set by set and triangle
+        // by triangle with a scalar branch each: ~40 cycles per branch, 350-400 per parking event, 17 % of a bounce.)  A finite
+        // threshold means finite operands and edge values below 2^7 * 1e30 in magnitude, hence finite minima; a NaN threshold passes all.
+        auto append = [&](uint32_t tile, uint32_t mask) {
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(mask != 0u);
+            uint32_t pre = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            asm volatile("" : "+v"(pre));                       // (keeps the prefix count out of a branch on "any lane active")
+            queue[mask ? qn + pre : Cfg::kQueue - 1u] = make_uint2((uint32_t)lane | (tile << 8), mask);
+            qn += (uint32_t)__popcll(m);
             if (qn >= Cfg::kDrain) flush();
-            RT_STAMP(ts_p1);
-            RT_STAMP_ADD(tt_park, ts_p0, ts_p1);
         };
+        auto park_a = [&](uint32_t tile) { RT_STAMP(ts_p0); uint32_t mask; RT_MASK_A(mask); append(tile, mask); RT_STAMP(ts_p1); RT_STAMP_ADD(tt_park, ts_p0, ts_p1); };
+        auto park_b = [&](uint32_t tile) { RT_STAMP(ts_p0); uint32_t mask; RT_MASK_B(mask); append(tile, mask); RT_STAMP(ts_p1); RT_STAMP_ADD(tt_park, ts_p0, ts_p1); };
         RT_STAMP(ts_rays);
         RT_STAMP_ADD(tt_rays, ts_iter, ts_rays);
 
@@ -444,20 +451,20 @@ scan_solo_kernel(SceneView sc, WaveBuffers wb, MfView mf, uint32_t bounce, uint3
                 RT_TRIP(ay, ax);
                 ay = tile_row(); ax = tile_row();
                 if (__builtin_expect((any_a | any_b) != 0ull, 0)) {
-                    if (any_a) park(t - 1u, MA0, MA1, MA2, MA3);
-                    if (any_b) park(t, MB0, MB1, MB2, MB3);
+                    if (any_a) park_a(t - 1u);
+                    if (any_b) park_b(t);
                 }
             }
             // epilogue: a last single stage if the segment's tile count is even, then the examination of the last tile (park() finds
             // nothing when there is nothing)
             if (t < t1) {
                 RT_STAGE_Y(ay);
-                if (any_a) park(t - 1u, MA0, MA1, MA2, MA3);
+                if (any_a) park_a(t - 1u);
                 RT_EXAMINE_Y();
-                park(t, MB0, MB1, MB2, MB3);
+                park_b(t);
             } else {
                 RT_EXAMINE_X();
-                park(t - 1u, MA0, MA1, MA2, MA3);
+                park_a(t - 1u);
             }
             }
             ts0 = ts1;
@@ -471,7 +478,6 @@ scan_solo_kernel(SceneView sc, WaveBuffers wb, MfView mf, uint32_t bounce, uint3
 #ifdef RT_SOLO_STAMPS
         tt_iters++;
 #endif
-        c_cand_total += (lane == 0) ? n_total : 0u;
     }
 #ifdef RT_SOLO_STAMPS
     if (lane == 0 && mf.dbg_log) {
@@ -485,14 +491,14 @@ scan_solo_kernel(SceneView sc, WaveBuffers wb, MfView mf, uint32_t bounce, uint3
     if (lane == 0) wb.cand_counts[region] = (uint32_t)(appended < (unsigned long long)wb.cand_region ? appended : (unsigned long long)wb.cand_region);
     if (lane == 0 && appended > (unsigned long long)*wb.cand_peak) atomicMax(wb.cand_peak, (uint32_t)(appended < 0xFFFFFFF0ull ? appended : 0xFFFFFFF0ull));   // (racy pre-check: only saves atomics)
     if (kCount) {
-        atomicAdd(&counters->candidates, c_cand_total);
+        if (c_cand_lane) atomicAdd(&counters->candidates, c_cand_lane);
         if (c_culled) atomicAdd(&counters->culled_tests, c_culled);
         if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&counters->tri_tests, (unsigned long long)n_rays * (v_chunk_end - v_chunk_begin));
     }
 }
 
-// ---- narrow phase: one lane per surviving (ray, triangle) pair, exact reference-order test (:243-249), atomicMin merge.
-// One block per wave region of the scan launch that preceded it (grid-stride over regions).
+// ---- narrow phase: one lane per record (ray, first storage position << 5 | 5-bit survivor mask): exact reference-order test
+// (:243-249) of every marked triangle, atomicMin merge.  One block per wave region of the scan launch that preceded it.
 __global__ void __launch_bounds__(256) narrow_phase_kernel(SceneView sc, WaveBuffers wb, MfView mf, uint32_t bounce, uint32_t n_regions)
 {
     const RayQueue qin = (bounce & 1u) ? wb.q[1] : wb.q[0];
@@ -502,7 +508,13 @@ __global__ void __launch_bounds__(256) narrow_phase_kernel(SceneView sc, WaveBuf
         const uint2 *cand = wb.cand + (size_t)r * wb.cand_region;
         for (uint32_t i = threadIdx.x; i < n; i += 256u) {
             const uint2 c = cand[i];
-            if (c.x != 0xFFFFFFFFu) exact_and_merge(sc, qin, best, c.x, mf.order[c.y]);
+            uint32_t um = c.y & 31u;
+            const uint32_t pos5 = c.y >> 5;
+            while (um) {
+                const uint32_t pos = pos5 + (uint32_t)__builtin_ctz(um);
+                um &= um - 1u;
+                if (pos < sc.n_tri_visits) exact_and_merge(sc, qin, best, c.x, mf.order[pos]);     // (padding rows behind the last triangle)
+            }
         }
     }
 }
