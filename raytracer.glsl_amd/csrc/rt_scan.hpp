@@ -131,7 +131,8 @@ struct SoloCfg {
 //     Y0..Y3 = v[192:207] v[208:223] v[224:239] v[240:255]
 //     MA0..3 = v[96:103] v[104:111] v[112:119] v[120:127]       minima (5 per set, slot 5 = their maximum) written by a Y stage
 //     MB0..3 = v[64:71]  v[72:79]   v[80:87]   v[88:95]         ... by an X stage
-//     KA = s[20:27], KB = s[28:35]                              "lanes with a survivor" per ray set of the last Y / X stage
+//     KA = s[36:43], KB = s[44:51]                              "lanes with a survivor" per ray set of the first / second stage of a trip
+//                                                               (s32..s34 are the ABI's stack / frame registers: kept clear of)
 // The blocks are bound with physical-register constraints, so the compiler sees ordinary dataflow (it keeps its own values out of
 // the way and orders loads and waits), while the ORDER inside a statement is exactly what is written.
 //
@@ -160,14 +161,14 @@ struct SoloCfg {
     "v_cmp_nle_f32_e64 s[" #KL ":" #KL "+1], v[" #ML "+5], " TH "\n\t"
 #define RT_MFMA(NL, AOP, B) "v_mfma_f32_32x32x16_bf16 v[" #NL ":" #NL "+15], " AOP ", " B ", 0\n\t"
 #define RT_FOLD(ANY, KL) "s_or_b64 " ANY ", s[" #KL ":" #KL "+1], s[" #KL "+2:" #KL "+3]\n\ts_or_b64 " ANY ", " ANY ", s[" #KL "+4:" #KL "+5]\n\ts_or_b64 " ANY ", " ANY ", s[" #KL "+6:" #KL "+7]\n\t"
-#define RT_STAGE_Y_TEXT(AOP) RT_MFMA(192, AOP, "%[b0]") RT_EXAM(128, 96, 20, "%[t0]") RT_MFMA(208, AOP, "%[b1]") RT_EXAM(144, 104, 22, "%[t1]") \
-                             RT_MFMA(224, AOP, "%[b2]") RT_EXAM(160, 112, 24, "%[t2]") RT_MFMA(240, AOP, "%[b3]") RT_EXAM(176, 120, 26, "%[t3]")
-#define RT_STAGE_X_TEXT(AOP) RT_MFMA(128, AOP, "%[b0]") RT_EXAM(192, 64, 28, "%[t0]") RT_MFMA(144, AOP, "%[b1]") RT_EXAM(208, 72, 30, "%[t1]") \
-                             RT_MFMA(160, AOP, "%[b2]") RT_EXAM(224, 80, 32, "%[t2]") RT_MFMA(176, AOP, "%[b3]") RT_EXAM(240, 88, 34, "%[t3]")
-#define RT_K_CLOBBERS "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27", "s28", "s29", "s30", "s31", "s32", "s33", "s34", "s35"
+#define RT_STAGE_Y_TEXT(AOP) RT_MFMA(192, AOP, "%[b0]") RT_EXAM(128, 96, 36, "%[t0]") RT_MFMA(208, AOP, "%[b1]") RT_EXAM(144, 104, 38, "%[t1]") \
+                             RT_MFMA(224, AOP, "%[b2]") RT_EXAM(160, 112, 40, "%[t2]") RT_MFMA(240, AOP, "%[b3]") RT_EXAM(176, 120, 42, "%[t3]")
+#define RT_STAGE_X_TEXT(AOP) RT_MFMA(128, AOP, "%[b0]") RT_EXAM(192, 64, 44, "%[t0]") RT_MFMA(144, AOP, "%[b1]") RT_EXAM(208, 72, 46, "%[t1]") \
+                             RT_MFMA(160, AOP, "%[b2]") RT_EXAM(224, 80, 48, "%[t2]") RT_MFMA(176, AOP, "%[b3]") RT_EXAM(240, 88, 50, "%[t3]")
+#define RT_K_CLOBBERS "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51"
 // two stages: tile t (operand AY) -> Y while X (tile t-1) is examined into MA; tile t+1 (operand AX) -> X while Y is examined into MB
 #define RT_TRIP(AY, AX) \
-    asm volatile(RT_STAGE_Y_TEXT("%[ay]") RT_STAGE_X_TEXT("%[ax]") RT_FOLD("%[anya]", 20) RT_FOLD("%[anyb]", 28) \
+    asm volatile(RT_STAGE_Y_TEXT("%[ay]") RT_STAGE_X_TEXT("%[ax]") RT_FOLD("%[anya]", 36) RT_FOLD("%[anyb]", 44) \
                  : "+{v[128:143]}"(X0), "+{v[144:159]}"(X1), "+{v[160:175]}"(X2), "+{v[176:191]}"(X3), \
                    "=&{v[192:207]}"(Y0), "=&{v[208:223]}"(Y1), "=&{v[224:239]}"(Y2), "=&{v[240:255]}"(Y3), \
                    "=&{v[96:103]}"(MA0), "=&{v[104:111]}"(MA1), "=&{v[112:119]}"(MA2), "=&{v[120:127]}"(MA3), \
@@ -177,7 +178,7 @@ struct SoloCfg {
 // a single stage (a segment with an even number of tiles ends with one), the products of a segment's first tile, and the
 // examination of its last one (nothing to overlap with)
 #define RT_STAGE_Y(AY) \
-    asm volatile(RT_STAGE_Y_TEXT("%[ay]") RT_FOLD("%[anya]", 20) \
+    asm volatile(RT_STAGE_Y_TEXT("%[ay]") RT_FOLD("%[anya]", 36) \
                  : "=&{v[192:207]}"(Y0), "=&{v[208:223]}"(Y1), "=&{v[224:239]}"(Y2), "=&{v[240:255]}"(Y3), \
                    "=&{v[96:103]}"(MA0), "=&{v[104:111]}"(MA1), "=&{v[112:119]}"(MA2), "=&{v[120:127]}"(MA3), [anya] "=&s"(any_a) \
                  : "{v[128:143]}"(X0), "{v[144:159]}"(X1), "{v[160:175]}"(X2), "{v[176:191]}"(X3), \
@@ -188,12 +189,12 @@ struct SoloCfg {
                  : "=&{v[128:143]}"(X0), "=&{v[144:159]}"(X1), "=&{v[160:175]}"(X2), "=&{v[176:191]}"(X3) \
                  : [a] "v"(AOP), [b0] "v"(B0), [b1] "v"(B1), [b2] "v"(B2), [b3] "v"(B3))
 #define RT_EXAMINE_X() \
-    asm volatile("s_nop 15\n\t" RT_EXAM(128, 96, 20, "%[t0]") RT_EXAM(144, 104, 22, "%[t1]") RT_EXAM(160, 112, 24, "%[t2]") RT_EXAM(176, 120, 26, "%[t3]") "s_nop 7" \
+    asm volatile("s_nop 15\n\t" RT_EXAM(128, 96, 36, "%[t0]") RT_EXAM(144, 104, 38, "%[t1]") RT_EXAM(160, 112, 40, "%[t2]") RT_EXAM(176, 120, 42, "%[t3]") "s_nop 7" \
                  : "=&{v[96:103]}"(MA0), "=&{v[104:111]}"(MA1), "=&{v[112:119]}"(MA2), "=&{v[120:127]}"(MA3) \
                  : "{v[128:143]}"(X0), "{v[144:159]}"(X1), "{v[160:175]}"(X2), "{v[176:191]}"(X3), [t0] "v"(th0), [t1] "v"(th1), [t2] "v"(th2), [t3] "v"(th3) \
                  : RT_K_CLOBBERS)
 #define RT_EXAMINE_Y() \
-    asm volatile("s_nop 15\n\t" RT_EXAM(192, 64, 28, "%[t0]") RT_EXAM(208, 72, 30, "%[t1]") RT_EXAM(224, 80, 32, "%[t2]") RT_EXAM(240, 88, 34, "%[t3]") "s_nop 7" \
+    asm volatile("s_nop 15\n\t" RT_EXAM(192, 64, 44, "%[t0]") RT_EXAM(208, 72, 46, "%[t1]") RT_EXAM(224, 80, 48, "%[t2]") RT_EXAM(240, 88, 50, "%[t3]") "s_nop 7" \
                  : "=&{v[64:71]}"(MB0), "=&{v[72:79]}"(MB1), "=&{v[80:87]}"(MB2), "=&{v[88:95]}"(MB3) \
                  : "{v[192:207]}"(Y0), "{v[208:223]}"(Y1), "{v[224:239]}"(Y2), "{v[240:255]}"(Y3), [t0] "v"(th0), [t1] "v"(th1), [t2] "v"(th2), [t3] "v"(th3) \
                  : RT_K_CLOBBERS)

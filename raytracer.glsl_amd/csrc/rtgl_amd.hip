@@ -192,6 +192,7 @@ struct rtgl_context {
     float4 *d_packets = nullptr; uint32_t packets_capacity = 0;
     uint2 *d_cand = nullptr; uint32_t cand_regions = 0, cand_region_pairs = 0, cand_region_target = 0; bool cand_fixed = false;
     bool solo_attr_set = false;              // hipFuncAttributeMaxDynamicSharedMemorySize is per device: raised once per context (= per device binding)
+    bool group_explicit = false;             // "mf_group_quads" was set through rtgl_set_option
     bool kernel_explicit = false;            // "kernel" was set through rtgl_set_option or RTGL_AMD_KERNEL
     uint32_t counts_n0 = 0, counts_len = 0;
     std::vector<uint32_t> est_counts;        // grid-size estimates for the next frame
@@ -569,7 +570,9 @@ static int rebuild_triangles(rtgl_context *ctx)
         if (ctx->d_mf_A) { HIPCHK(ctx, hipFree(ctx->d_mf_A)); ctx->d_mf_A = nullptr; }
         if (ctx->d_mf_order) { HIPCHK(ctx, hipFree(ctx->d_mf_order)); ctx->d_mf_order = nullptr; }
         if (ctx->d_mf_cull) { HIPCHK(ctx, hipFree(ctx->d_mf_cull)); ctx->d_mf_cull = nullptr; }
-        ctx->mf_group_quads = (uint32_t)ctx->opt_mf_group_quads;
+        // quads sharing one local origin: 32 unless the caller chose; a dense mesh (>= 50k triangles) gets 8 -- its triangles are small
+        // against the group, so the survivors (and the time spent parking them) follow the group size more than at 10k (C4: +7 %)
+        ctx->mf_group_quads = ctx->group_explicit ? (uint32_t)ctx->opt_mf_group_quads : (visit_tri.size() >= 50000 ? 8u : 32u);
         const uint32_t group_tris = ctx->mf_group_quads * kMfQuadTris;
         ctx->n_mf_groups = (ctx->n_tri_visits + group_tris - 1) / group_tris;
         const std::vector<uint32_t> order = morton_order(ctx, visit_tri);
@@ -1137,8 +1140,8 @@ extern "C" int rtgl_set_option(rtgl_context *ctx, const char *key, int value)
         ctx->opt_cull = value;
     } else if (!strcmp(key, "mf_group_quads")) {
         if (value < 1 || value > (int)kMfMaxGroupQuads || (value & (value - 1))) return fail(ctx, RTGL_ERR_INVALID, "mf_group_quads must be a power of two in [1, 64]");
-        if (value != ctx->opt_mf_group_quads) ctx->tris_dirty = true;                          // local origins and A tiles are per group
-        ctx->opt_mf_group_quads = value;
+        if (value != (int)ctx->mf_group_quads) ctx->tris_dirty = true;                         // local origins and A tiles are per group
+        ctx->opt_mf_group_quads = value; ctx->group_explicit = true;
     } else if (!strcmp(key, "wf_packed")) {
         ctx->opt_wf_packed = value != 0;
     } else if (!strcmp(key, "wf_early")) {
@@ -1171,7 +1174,7 @@ extern "C" int rtgl_get_option(rtgl_context *ctx, const char *key, int *value)
     else if (!strcmp(key, "wf_packed")) *value = ctx->opt_wf_packed;
     else if (!strcmp(key, "mf_sets")) *value = kSoloSets;
     else if (!strcmp(key, "mf_chunk_quads")) *value = ctx->opt_mf_chunk_quads;
-    else if (!strcmp(key, "mf_group_quads")) *value = ctx->opt_mf_group_quads;
+    else if (!strcmp(key, "mf_group_quads")) *value = (int)ctx->mf_group_quads;
     else if (!strcmp(key, "cull")) *value = ctx->opt_cull;
     else if (!strcmp(key, "rng_state")) *value = ctx->opt_rng_state;
     else if (!strcmp(key, "counters")) *value = ctx->opt_counters;
