@@ -355,27 +355,35 @@ scan_solo_kernel(SceneView sc, WaveBuffers wb, MfView mf, uint32_t bounce, uint3
 
         uint32_t qn = 0;                                        // wave-uniform
         auto flush = [&]() {
-            // Every queue entry becomes four records (queue slot of the ray, storage position of the lane's first triangle << 5 | the
-            // 5-bit survivor mask of that ray set), appended to the wave's region coalesced, fire and forget; the narrow phase expands
-            // the masks and maps storage position -> visit index.  What does not fit gets its exact tests right here, so the result
-            // never depends on the buffer size.  `appended` is 64 bits wide: a degenerate scene (NaN bounds: every pair survives) can
-            // exceed 2^32 records per wave.
-            for (uint32_t j = (uint32_t)lane; j < 4u * qn; j += 64u) {      // record j = (entry j / 4, ray set j % 4)
-                const uint2 e = queue[j >> 2];
-                const uint32_t rs = j & 3u, ln = e.x & 63u, pos5 = v_chunk_begin + (e.x >> 8) * kMfTileTris + 5u * (ln >> 5);
-                if (kCount && rs == 0u) c_cand_lane += (unsigned long long)__popc(e.y);
-                uint32_t um = debug_skip_exact == 0 ? (e.y >> (5u * rs)) & 31u : 0u;
-                const uint32_t slot = wave_slot0 + rs * 32u + (ln & 31u);
-                const unsigned long long at = appended + (unsigned long long)j;
-                if (at < (unsigned long long)wb.cand_region) cand[at] = make_uint2(slot, (pos5 << 5) | um);
-                else
-                    while (um) {
-                        const uint32_t pos = pos5 + (uint32_t)__builtin_ctz(um);
-                        um &= um - 1u;
-                        if (pos < v_chunk_end) exact_and_merge(sc, qin, best, slot, mf.order[pos]);
+            // Every (queue entry, ray set) with a non-empty 5-bit mask becomes one record (queue slot of the ray, storage position of the
+            // lane's first triangle << 5 | mask), appended densely to the wave's region (ballot + prefix count per ray set), fire and
+            // forget; the narrow phase expands the masks and maps storage position -> visit index.  What does not fit gets its exact
+            // tests right here, so the result never depends on the buffer size.  `appended` is 64 bits wide: a degenerate scene (NaN
+            // bounds: every pair survives) can exceed 2^32 records per wave.
+            for (uint32_t i0 = 0; i0 < qn; i0 += 64u) {
+                const uint32_t i = i0 + (uint32_t)lane;
+                const uint2 e = i < qn ? queue[i] : make_uint2(0u, 0u);
+                const uint32_t ln = e.x & 63u, pos5 = v_chunk_begin + (e.x >> 8) * kMfTileTris + 5u * (ln >> 5);
+                if (kCount) c_cand_lane += (unsigned long long)__popc(e.y);
+                const uint32_t bits = debug_skip_exact == 0 ? e.y : 0u;
+#pragma unroll
+                for (int s = 0; s < S; ++s) {
+                    uint32_t um = (bits >> (5 * s)) & 31u;
+                    const unsigned long long m = __builtin_amdgcn_ballot_w64(um != 0u);
+                    const unsigned long long at = appended + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                    const uint32_t slot = wave_slot0 + (uint32_t)(s * 32) + (ln & 31u);
+                    if (um != 0u) {
+                        if (at < (unsigned long long)wb.cand_region) cand[at] = make_uint2(slot, (pos5 << 5) | um);
+                        else
+                            while (um) {
+                                const uint32_t pos = pos5 + (uint32_t)__builtin_ctz(um);
+                                um &= um - 1u;
+                                if (pos < v_chunk_end) exact_and_merge(sc, qin, best, slot, mf.order[pos]);
+                            }
                     }
+                    appended += (unsigned long long)__popcll(m);
+                }
             }
-            appended += 4ull * qn;
             qn = 0;
         };
 
