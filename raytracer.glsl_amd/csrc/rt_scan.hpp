@@ -175,6 +175,21 @@ struct SoloCfg {
                    "=&{v[64:71]}"(MB0), "=&{v[72:79]}"(MB1), "=&{v[80:87]}"(MB2), "=&{v[88:95]}"(MB3), [anya] "=&s"(any_a), [anyb] "=&s"(any_b) \
                  : [ay] "v"(AY), [ax] "v"(AX), [b0] "v"(B0), [b1] "v"(B1), [b2] "v"(B2), [b3] "v"(B3), [t0] "v"(th0), [t1] "v"(th1), [t2] "v"(th2), [t3] "v"(th3) \
                  : RT_K_CLOBBERS)
+// the same trip, which also issues the LDS reads of the tile rows two trips ahead (into NY, NX; `addr` = LDS byte address of the
+// next row to read, advanced by two rows) right behind its first matrix instruction and waits for them at its end, when they have
+// long landed: nothing of the tile fetch is left for the scalar spot between two trips
+#define RT_TRIP_L(AY, AX, NY, NX, ADDR) \
+    asm volatile(RT_MFMA(192, "%[ay]", "%[b0]") "ds_read_b128 %[ny], %[addr]\n\tds_read_b128 %[nx], %[addr] offset:1024\n\tv_add_u32_e32 %[addr], 0x800, %[addr]\n\t" \
+                 RT_EXAM(128, 96, 36, "%[t0]") RT_MFMA(208, "%[ay]", "%[b1]") RT_EXAM(144, 104, 38, "%[t1]") \
+                 RT_MFMA(224, "%[ay]", "%[b2]") RT_EXAM(160, 112, 40, "%[t2]") RT_MFMA(240, "%[ay]", "%[b3]") RT_EXAM(176, 120, 42, "%[t3]") \
+                 RT_STAGE_X_TEXT("%[ax]") "s_waitcnt lgkmcnt(0)\n\t" RT_FOLD("%[anya]", 36) RT_FOLD("%[anyb]", 44) \
+                 : "+{v[128:143]}"(X0), "+{v[144:159]}"(X1), "+{v[160:175]}"(X2), "+{v[176:191]}"(X3), \
+                   "=&{v[192:207]}"(Y0), "=&{v[208:223]}"(Y1), "=&{v[224:239]}"(Y2), "=&{v[240:255]}"(Y3), \
+                   "=&{v[96:103]}"(MA0), "=&{v[104:111]}"(MA1), "=&{v[112:119]}"(MA2), "=&{v[120:127]}"(MA3), \
+                   "=&{v[64:71]}"(MB0), "=&{v[72:79]}"(MB1), "=&{v[80:87]}"(MB2), "=&{v[88:95]}"(MB3), [anya] "=&s"(any_a), [anyb] "=&s"(any_b), \
+                   [ny] "=&v"(NY), [nx] "=&v"(NX), [addr] "+v"(ADDR) \
+                 : [ay] "v"(AY), [ax] "v"(AX), [b0] "v"(B0), [b1] "v"(B1), [b2] "v"(B2), [b3] "v"(B3), [t0] "v"(th0), [t1] "v"(th1), [t2] "v"(th2), [t3] "v"(th3) \
+                 : RT_K_CLOBBERS, "memory")
 // a single stage (a segment with an even number of tiles ends with one), the products of a segment's first tile, and the
 // examination of its last one (nothing to overlap with)
 #define RT_STAGE_Y(AY) \
@@ -261,11 +276,11 @@ scan_solo_kernel(SceneView sc, WaveBuffers wb, MfView mf, uint32_t bounce, uint3
         }
         // the chunk's cull records behind the tiles (and the two spare rows): one 64-byte record per quad
         const uint4 *csrc = reinterpret_cast<const uint4 *>(mf.cull + q_begin);
-        uint4 *cdst = lds_tiles + (size_t)(chunk_quads * kMfQuadTiles + 2u) * 64u;
+        uint4 *cdst = lds_tiles + (size_t)(chunk_quads * kMfQuadTiles + 4u) * 64u;
         if (threadIdx.x < (q_end - q_begin) * 4u) cdst[threadIdx.x] = csrc[threadIdx.x];
         __syncthreads();
     }
-    const MfCull *lds_cull = reinterpret_cast<const MfCull *>(lds_tiles + (size_t)(chunk_quads * kMfQuadTiles + 2u) * 64u);
+    const MfCull *lds_cull = reinterpret_cast<const MfCull *>(lds_tiles + (size_t)(chunk_quads * kMfQuadTiles + 4u) * 64u);
     unsigned long long c_culled = 0;
     RT_STAMP(ts_staged);
     RT_STAMP_ADD(tt_stage, ts_begin, ts_staged);
@@ -447,22 +462,36 @@ scan_solo_kernel(SceneView sc, WaveBuffers wb, MfView mf, uint32_t bounce, uint3
             const uint32_t run = inv ? (uint32_t)__builtin_ctz(inv) : 32u - qs;
             seg &= ~((run >= 32u ? 0xFFFFFFFFu : ((1u << run) - 1u)) << qs);
             const uint32_t t0 = qs * kMfQuadTiles, t1 = (qs + run) * kMfQuadTiles;
-            // prologue: the products of the segment's first tile.  The tile rows of a trip are read during the trip before; the two rows
-            // behind the chunk's last tile are allocated (and never used).
+            // prologue: the products of the segment's first tile.  The tile rows of a trip are read two trips ahead (by the trip
+            // statement itself); the four rows behind the chunk's last tile are allocated (and never used).
             const uint4 *row = lds_tiles + (size_t)t0 * 64u + l_lane;
             auto tile_row = [&]() { const uint4 r = *row; row += 64; return u32x4{r.x, r.y, r.z, r.w}; };
-            u32x4 ap = tile_row(), ay = tile_row(), ax = tile_row();
+            u32x4 ap = tile_row(), ay = tile_row(), ax = tile_row(), by, bx;
+            typedef const uint4 __attribute__((address_space(3))) *LdsRow;
+            uint32_t addr = (uint32_t)(uintptr_t)(LdsRow)row;                           // LDS byte address of tile t0 + 3's row
             RT_PRODUCTS_X(ap);
             // steady state: two stages per trip (tile t -> Y beside the examination of tile t-1, tile t+1 -> X beside the examination
-            // of tile t), so that X and Y swap roles without moves
+            // of tile t), so that X and Y swap roles without moves; two trips per loop iteration, so that the tile rows do, too
             uint32_t t = t0 + 1u;
-            for (; t + 1u < t1; t += 2u) {
-                RT_TRIP(ay, ax);
-                ay = tile_row(); ax = tile_row();
+            for (; t + 3u < t1; t += 4u) {
+                RT_TRIP_L(ay, ax, by, bx, addr);
                 if (__builtin_expect((any_a | any_b) != 0ull, 0)) {
                     if (any_a) park_a(t - 1u);
                     if (any_b) park_b(t);
                 }
+                RT_TRIP_L(by, bx, ay, ax, addr);
+                if (__builtin_expect((any_a | any_b) != 0ull, 0)) {
+                    if (any_a) park_a(t + 1u);
+                    if (any_b) park_b(t + 2u);
+                }
+            }
+            if (t + 1u < t1) {                                                           // two or three tiles left: one more trip
+                RT_TRIP_L(ay, ax, by, bx, addr);
+                if ((any_a | any_b) != 0ull) {
+                    if (any_a) park_a(t - 1u);
+                    if (any_b) park_b(t);
+                }
+                ay = by; t += 2u;
             }
             // epilogue: a last single stage if the segment's tile count is even, then the examination of the last tile (park() finds
             // nothing when there is nothing)

@@ -735,7 +735,7 @@ static int launch_intersect_solo(rtgl_context *ctx, const SceneView &sc, uint32_
     const uint32_t chunks = (real_quads + chunk_quads - 1) / chunk_quads;
     // one block per CU in total: with more, the surplus runs as a second, mostly empty round
     const uint32_t blocks_x = std::max(1u, std::min(blocks_x_all, (uint32_t)ctx->n_cus / chunks));
-    const size_t lds = std::max<size_t>(((size_t)chunk_quads * kMfQuadTiles + 2) * 1024 + (size_t)chunk_quads * sizeof(MfCull), 96 * 1024);   // + the two rows read a trip ahead behind the last tile; > half of the CU's LDS with the static queue: one block per CU
+    const size_t lds = std::max<size_t>(((size_t)chunk_quads * kMfQuadTiles + 4) * 1024 + (size_t)chunk_quads * sizeof(MfCull), 96 * 1024);   // + the four rows read two trips ahead behind the last tile; > half of the CU's LDS with the static queue: one block per CU
 #ifdef RT_SOLO_STAMPS
     if (!ctx->d_dbg_log) { HIPCHK(ctx, hipMalloc((void **)&ctx->d_dbg_log, (size_t)(2 + (2u << 22)) * 4)); HIPCHK(ctx, hipMemsetAsync(ctx->d_dbg_log, 0, 16 * 8 * 64, ctx->stream)); }
 #endif
