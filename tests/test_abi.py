@@ -43,6 +43,18 @@ def test_create_fails_loudly_without_a_device(rt):
     assert b"no HIP device" in lib.rtgl_last_error(None) or b"hip" in lib.rtgl_last_error(None).lower()
     with pytest.raises(rt.host.RtglError):
         rt.host.Context(64, 64)
+    rc = lib.rtgl_create_multi(C.byref(h), 64, 64, (C.c_int * 2)(0, 1), 2, 8)           # the multi-device form fails the same way
+    assert rc < 0 and not h.value
+    with pytest.raises(rt.host.RtglError):
+        rt.host.Context(64, 64, devices=[0, 0])
+
+
+def test_multi_device_arguments_are_checked(rt):
+    lib = rt.host.load_library()
+    h = C.c_void_p()
+    assert lib.rtgl_create_multi(C.byref(h), 64, 64, None, 2, 8) < 0 and not h.value
+    assert lib.rtgl_create_multi(C.byref(h), 64, 64, (C.c_int * 1)(0), 0, 8) < 0 and not h.value
+    assert lib.rtgl_device_count(None) < 0
 
 
 def test_product_never_imports_the_oracle():
