@@ -80,6 +80,7 @@ def main():
     ap.add_argument("--debug-skip-exact", type=int, default=None, help="diagnostic (wrong image): 1 drops the broad-phase survivors, 2 lets nothing survive")
     ap.add_argument("--mf-chunk-quads", type=int, default=None, help="kernel 4: 40-triangle quads per LDS-resident chunk (1..32)")
     ap.add_argument("--mf-group-quads", type=int, default=None, help="kernel 4: quads sharing one local origin (1, 2, 4 .. 64)")
+    ap.add_argument("--cull", type=int, default=None, help="kernel 4 packet culling: 0 off, 1 camera-ray bounce (default), 2 every bounce")
     ap.add_argument("--debug-bounces", type=int, default=None, help="diagnostic: override the bounce limit of the configuration (not the named workload)")
     ap.add_argument("--strip-rows", type=int, default=8, help="rows per interleaved strip (multiple of 8); 8 balances the ranks to +-3%% at N = 8, 16 to +-6%%")
     ap.add_argument("--timing-period", type=int, default=None, help="frames between kernel-timed frames (default: 1 at N = 1, 4 for N > 1)")
@@ -118,7 +119,7 @@ def main():
     ctx = rt.host.Context(W, H, device=local_rank, rank=rank, world=world, strip_rows=args.strip_rows)
     ctx.upload_scene(scene)
     for key, val in (("kernel", args.kernel), ("wf_rays", args.wf_rays), ("wf_mode", args.wf_mode), ("wf_chunk", args.wf_chunk), ("wf_early", args.wf_early), ("wf_packed", args.wf_packed),
-                     ("mf_chunk_quads", args.mf_chunk_quads), ("mf_group_quads", args.mf_group_quads), ("debug_skip_exact", args.debug_skip_exact)):
+                     ("mf_chunk_quads", args.mf_chunk_quads), ("cull", args.cull), ("mf_group_quads", args.mf_group_quads), ("debug_skip_exact", args.debug_skip_exact)):
         if val is not None:
             ctx.set_option(key, val)
     gat = rt.tiling.FrameGatherer(W, H, rank, world, dev, args.strip_rows)
