@@ -187,7 +187,7 @@ struct rtgl_context {
     int kernel_in_use = -1;                  // variant the last frame actually ran
     int n_cus = 256;
     // kernel 4 candidate buffer: one region per wave of a scan launch.  Sized from what the scene needs, not from the image: it starts
-    // at 4 records per ray and grows to 1.25 x the fullest region any finished frame reported (records that do not fit are tested
+    // at one record per ray and grows to 1.25 x the fullest region any finished frame reported (records that do not fit are tested
     // in place by the scan, so every size is correct; a too small one is only slower)
     float4 *d_packets = nullptr; uint32_t packets_capacity = 0;
     uint2 *d_cand = nullptr; uint32_t cand_regions = 0, cand_region_pairs = 0, cand_region_target = 0; bool cand_fixed = false;
@@ -629,7 +629,7 @@ static int ensure_wave_buffers(rtgl_context *ctx, uint32_t n0, uint32_t max_boun
     if (ctx->opt_kernel == RTGL_KERNEL_WAVEFRONT_MFMA_SOLO) {
         const uint32_t need_regions = solo_regions(ctx);
         // (a record = one (ray, 5-triangle mask); every queue entry of the scan makes four of them)
-        if (!ctx->cand_region_target) ctx->cand_region_target = std::max<uint32_t>(4096u, (uint32_t)std::min<uint64_t>(((uint64_t)n0 * 4 + need_regions - 1) / need_regions, 0xFFFFFFF0u));
+        if (!ctx->cand_region_target) ctx->cand_region_target = std::max<uint32_t>(4096u, (uint32_t)std::min<uint64_t>(((uint64_t)n0 + need_regions - 1) / need_regions, 0xFFFFFFF0u));
         if (!ctx->d_cand || need_regions > ctx->cand_regions || ctx->cand_region_target > ctx->cand_region_pairs) {
             if (ctx->d_cand) { HIPCHK(ctx, hipFree(ctx->d_cand)); ctx->d_cand = nullptr; }                  // (hipFree waits for the frames in flight)
             ctx->cand_regions = need_regions; ctx->cand_region_pairs = ctx->cand_region_target;
