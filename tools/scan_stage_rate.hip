@@ -6,7 +6,7 @@
 //   2 nocmp     v_cmp (SGPR destination) replaced by a third v_max3
 //   3 valu      no MFMAs at all
 //   4 mfma      no VALU at all
-//   5 agpr      MFMA destinations in AGPRs (VALU reads as in 1)
+//   (5 agpr     MFMA destinations in AGPRs: measured 184, the same as 0; removed so that the kernel fits 256 registers for the x2 arms)
 //   6 split     MFMA, 4 VALU of set s, 4 VALU of set s-1 ... (distance between dependent VALU instructions >= 4)
 //   7 copy      per block: 8 v_mov of the MFMA-written block into scratch registers, nothing else (pure read cost)
 //   8..10       how the v_cmp results are consumed by scalar code (see the STAGE_SOR* macros)
@@ -123,8 +123,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define CLOB_V(a) "v" #a
 #define C8(a) CLOB_V(a##0), CLOB_V(a##1), CLOB_V(a##2), CLOB_V(a##3), CLOB_V(a##4), CLOB_V(a##5), CLOB_V(a##6), CLOB_V(a##7), CLOB_V(a##8), CLOB_V(a##9)
 
-template <int V>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) stage_rate(unsigned long long *out, int iters, float seed)
+template <int V, int WPS = 1>
+__global__ void __launch_bounds__(256 * WPS) __attribute__((amdgpu_waves_per_eu(WPS, WPS))) stage_rate(unsigned long long *out, int iters, float seed)
 {
     u32x4 a, b;
     a.x = 0x3f803f80u + threadIdx.x; a.y = 0x3f003e80u; a.z = 0x40003f80u; a.w = 0x3f803f00u;
@@ -150,17 +150,12 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
                        "v64","v65","v66","v67","v68","v69","v70","v71","v72","v73","v74","v75","v76","v77","v78","v79", \
                        "v80","v81","v82","v83","v84","v85","v86","v87","v88","v89","v90","v91","v92","v93","v94","v95", \
                        "v96","v97","v98","v99","v100","v101","v102","v103","v104","v105","v106","v107","v108","v109","v110","v111", \
-                       "v112","v113","v114","v115","v116","v117","v118","v119","v120","v121","v122","v123","v124","v125","v126","v127", \
-                       "a0","a1","a2","a3","a4","a5","a6","a7","a8","a9","a10","a11","a12","a13","a14","a15","a16","a17","a18","a19","a20","a21","a22","a23","a24","a25","a26","a27","a28","a29","a30","a31", \
-                       "a32","a33","a34","a35","a36","a37","a38","a39","a40","a41","a42","a43","a44","a45","a46","a47","a48","a49","a50","a51","a52","a53","a54","a55","a56","a57","a58","a59","a60","a61","a62","a63", \
-                       "a64","a65","a66","a67","a68","a69","a70","a71","a72","a73","a74","a75","a76","a77","a78","a79","a80","a81","a82","a83","a84","a85","a86","a87","a88","a89","a90","a91","a92","a93","a94","a95", \
-                       "a96","a97","a98","a99","a100","a101","a102","a103","a104","a105","a106","a107","a108","a109","a110","a111","a112","a113","a114","a115","a116","a117","a118","a119","a120","a121","a122","a123","a124","a125","a126","a127")
+                       "v112","v113","v114","v115","v116","v117","v118","v119","v120","v121","v122","v123","v124","v125","v126","v127")
         if (V == 0) RUN(STAGE_FULL);
         else if (V == 1) RUN(STAGE_OTHER);
         else if (V == 2) RUN(STAGE_NOCMP);
         else if (V == 3) RUN(STAGE_VALU);
         else if (V == 4) RUN(STAGE_MFMA);
-        else if (V == 5) RUN(STAGE_AGPR);
         else if (V == 7) RUN(STAGE_COPY);
         else if (V == 8) RUN(STAGE_SOR);
         else if (V == 9) RUN(STAGE_SOREND);
@@ -180,20 +175,20 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
     if (seed == 12345.0f) out[1] = (unsigned long long)(X0[0] + X1[1] + X2[2] + X3[3] + Y0[0] + Y1[1] + Y2[2] + Y3[3]);
 }
 
-template <int V> static void run(const char *name, unsigned long long *d, int cus)
+template <int V, int WPS = 1> static void run(const char *name, unsigned long long *d, int cus)
 {
     const int iters = 20000;
     (void)hipMemset(d, 0, 16);
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-    hipLaunchKernelGGL((stage_rate<V>), dim3(cus), dim3(256), 0, 0, d, 1000, 1.5f);       // warm-up
+    hipLaunchKernelGGL((stage_rate<V, WPS>), dim3(cus), dim3(256 * WPS), 0, 0, d, 1000, 1.5f);       // warm-up
     (void)hipMemset(d, 0, 16);
     (void)hipEventRecord(e0);
-    hipLaunchKernelGGL((stage_rate<V>), dim3(cus), dim3(256), 0, 0, d, iters, 1.5f);
+    hipLaunchKernelGGL((stage_rate<V, WPS>), dim3(cus), dim3(256 * WPS), 0, 0, d, iters, 1.5f);
     (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
     float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1);
     unsigned long long h[2]; (void)hipMemcpy(h, d, 16, hipMemcpyDeviceToHost);
-    const double cyc = (double)h[0] / (cus * 4.0) / (iters * 2.0);
-    printf("%-6s %7.1f cycles per stage (4 products), %6.1f per product; %.2f ms => %.2f GHz\n", name, cyc, cyc / 4.0, ms, (double)h[0] / (cus * 4.0) / (ms * 1e6));
+    const double cyc = (double)h[0] / (cus * 4.0 * WPS) / (iters * 2.0) / WPS;      // cycles of a SIMD per stage: two waves share it
+    printf("%-11s %7.1f cycles per stage (4 products), %6.1f per product; %.2f ms => %.2f GHz\n", name, cyc, cyc / 4.0, ms, (double)h[0] / (cus * 4.0) / (ms * 1e6));
     fflush(stdout);
 }
 
@@ -203,10 +198,12 @@ int main()
     unsigned long long *d; (void)hipMalloc(&d, 16);
     const int cus = prop.multiProcessorCount;
     run<0>("full", d, cus); run<1>("other", d, cus); run<2>("nocmp", d, cus); run<3>("valu", d, cus);
-    run<4>("mfma", d, cus); run<5>("agpr", d, cus); run<7>("copy", d, cus);
+    run<4>("mfma", d, cus); run<7>("copy", d, cus);
     run<8>("sor", d, cus); run<9>("sorend", d, cus); run<10>("sordefer", d, cus);
     run<11>("nop5", d, cus); run<12>("or3", d, cus); run<13>("br", d, cus); run<14>("or1", d, cus); run<15>("or1old", d, cus);
     run<16>("brscc", d, cus); run<17>("brvcc", d, cus); run<18>("brmid", d, cus); run<19>("fold", d, cus);
     run<0>("full", d, cus); run<13>("br", d, cus);
+    // two waves per SIMD (256 registers each): does a second wave fill the ~40-cycle holes scalar instructions tear into the stream?
+    run<0, 2>("full x2", d, cus); run<13, 2>("br x2", d, cus); run<8, 2>("sor x2", d, cus); run<9, 2>("sorend x2", d, cus); run<10, 2>("sordefer x2", d, cus);
     return 0;
 }
