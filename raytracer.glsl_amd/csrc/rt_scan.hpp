@@ -121,7 +121,7 @@ struct SoloCfg {
     static constexpr uint32_t kStepMax = 2u * 64u;                    // a trip examines two tiles; a tile adds at most one entry per lane
     static constexpr uint32_t kDrain = 192u;                          // the queue is handed over once it holds this many
     static constexpr uint32_t kQueue = kStepMax + kDrain + 1u;        // entries per wave (+ one scratch entry lanes without a survivor write to)
-    static constexpr uint32_t kRaysPerBlock = 4u * (uint32_t)kSoloSets * 32u;
+    static constexpr uint32_t kRaysPerWave = (uint32_t)kSoloSets * 32u;
 };
 
 // ---- the hand-ordered instruction stream ---------------------------------------------------------------------------------------
@@ -236,14 +236,21 @@ struct SoloCfg {
 #define RT_STAMP_ADD(acc, from, to)
 #endif
 
-template <bool kCount>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+// W = waves per SIMD.  W = 1: the wave owns the register file (256 + AGPRs) and hides its own latencies (rays of the next two
+// trips in flight).  W = 2: two waves share a SIMD, 256 registers each; a wave alone can issue one vector instruction per 4 cycles
+// while the SIMD executes one per 2, so the second wave's VALU work runs beside the first one's and the stream becomes bound by
+// the matrix pipe itself (tools/scan_stage_rate.hip: 33 cycles per product against 46); the second wave also fills the holes that
+// scalar instructions, branches and the parking path tear into the stream.  The W = 2 form keeps nothing ray-related live across
+// the tile loop (rays are re-read from the queue at every segment: the partner wave hides the round trip).
+template <bool kCount, int W>
+__global__ void __launch_bounds__(256 * W) __attribute__((amdgpu_waves_per_eu(W, W)))
 scan_solo_kernel(SceneView sc, WaveBuffers wb, MfView mf, uint32_t bounce, uint32_t chunk_quads, Counters *__restrict__ counters, int debug_skip_exact, int cull)
 {
     using Cfg = SoloCfg;
     constexpr int S = kSoloSets;
+    constexpr uint32_t kWaves = 4u * (uint32_t)W, kThreads = 256u * (uint32_t)W, kRaysPerBlock = kWaves * Cfg::kRaysPerWave;
     extern __shared__ uint4 lds_tiles[];                      // the chunk's A tiles, [quad][tile][panel][row]
-    __shared__ uint2 lds_queue[4 * Cfg::kQueue];             // per-wave survivor queue, entry = (lane | tile in chunk << 8, 20-bit mask: bit 5 s + u = triangle u of the lane's half survived for ray set s)
+    __shared__ uint2 lds_queue[kWaves * Cfg::kQueue];        // per-wave survivor queue, entry = (lane | tile in chunk << 8, 20-bit mask: bit 5 s + u = triangle u of the lane's half survived for ray set s)
     RT_STAMP(ts_begin);
 #ifdef RT_SOLO_STAMPS
     unsigned long long tt_stage = 0, tt_rays = 0, tt_group = 0, tt_steady = 0, tt_park = 0, tt_flush = 0, tt_iters = 0;
@@ -255,7 +262,7 @@ scan_solo_kernel(SceneView sc, WaveBuffers wb, MfView mf, uint32_t bounce, uint3
     // only quads that hold triangles; the padding rows inside the last one carry a -3e38 bias and never survive
     const uint32_t q_begin = blockIdx.y * chunk_quads, q_end = min(q_begin + chunk_quads, min(mf.n_quads, (sc.n_tri_visits + kMfQuadTris - 1u) / kMfQuadTris));
     // survivors of this wave go to ITS region of the candidate buffer: no atomic, no round trip the single wave of a SIMD would wait for
-    const uint32_t region = (blockIdx.y * gridDim.x + blockIdx.x) * 4u + (uint32_t)wave;
+    const uint32_t region = (blockIdx.y * gridDim.x + blockIdx.x) * kWaves + (uint32_t)wave;
     uint2 *const cand = wb.cand + (size_t)region * wb.cand_region;
     unsigned long long appended = 0;                           // wave-uniform; pairs beyond the region's capacity are tested in place
     if (q_begin >= q_end) { if (lane == 0) wb.cand_counts[region] = 0u; return; }
@@ -267,12 +274,12 @@ scan_solo_kernel(SceneView sc, WaveBuffers wb, MfView mf, uint32_t bounce, uint3
         const uint32_t n16 = (q_end - q_begin) * (kQuadBytes / 16u);
         const uint4 *src = mf.A + (size_t)q_begin * (kQuadBytes / 16u);
         // eight loads in flight per thread (a plain copy loop waits for every load: 32 exposed L2 round trips per launch)
-        for (uint32_t i0 = threadIdx.x; i0 < n16; i0 += 8u * 256u) {
+        for (uint32_t i0 = threadIdx.x; i0 < n16; i0 += 8u * kThreads) {
             uint4 v[8];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) { const uint32_t i = i0 + (uint32_t)k * 256u; v[k] = src[min(i, n16 - 1u)]; }
+            for (int k = 0; k < 8; ++k) { const uint32_t i = i0 + (uint32_t)k * kThreads; v[k] = src[min(i, n16 - 1u)]; }
 #pragma unroll
-            for (int k = 0; k < 8; ++k) { const uint32_t i = i0 + (uint32_t)k * 256u; if (i < n16) lds_tiles[i] = v[k]; }
+            for (int k = 0; k < 8; ++k) { const uint32_t i = i0 + (uint32_t)k * kThreads; if (i < n16) lds_tiles[i] = v[k]; }
         }
         // the chunk's cull records behind the tiles (and the two spare rows): one 64-byte record per quad
         const uint4 *csrc = reinterpret_cast<const uint4 *>(mf.cull + q_begin);
@@ -302,11 +309,25 @@ scan_solo_kernel(SceneView sc, WaveBuffers wb, MfView mf, uint32_t bounce, uint3
             if (slot < n_rays) { da[s] = qin.a[slot]; db[s] = qin.b[slot]; }
         }
     };
-    const uint32_t kStride = gridDim.x * Cfg::kRaysPerBlock;
-    fetch_rays(blockIdx.x * Cfg::kRaysPerBlock, nxt_a, nxt_b);
-    fetch_rays(blockIdx.x * Cfg::kRaysPerBlock + kStride, nx2_a, nx2_b);
+    const uint32_t kStride = gridDim.x * kRaysPerBlock;
+    if constexpr (W == 1) {
+        fetch_rays(blockIdx.x * kRaysPerBlock, nxt_a, nxt_b);
+        fetch_rays(blockIdx.x * kRaysPerBlock + kStride, nx2_a, nx2_b);
+    }
+    // the constants of a ray over the scan, from its queue record
+    auto prepare_ray = [&](MfRay &r, const float4 &a, const float4 &b, bool valid) {
+        r.valid = valid;
+        r.o = mk(a.x, a.y, a.z); r.d = mk(a.w, b.x, b.y);
+        r.wd = __builtin_amdgcn_sqrtf(dot3(r.d, r.d)) * 1.001f;               // (1 ulp square roots: these are bounds, inflated by 1.001)
+        r.wod = (__builtin_amdgcn_sqrtf(dot3(r.o, r.o)) * 1.001f) * r.wd;
+        const uint32_t dxy = pack_bf16(r.d.x, r.d.y);
+        r.dyz = pack_bf16(r.d.y, r.d.z);
+        r.dx_hi = dxy << 16;
+        const f3 dl = mk(r.d.x - __uint_as_float(dxy << 16), r.d.y - __uint_as_float(dxy & 0xffff0000u), r.d.z - __uint_as_float(r.dyz & 0xffff0000u));
+        r.tail = half ? pack_bf16(dl.y, dl.z) : pack_bf16(1.0f, dl.x);
+    };
 
-    for (uint32_t base = blockIdx.x * Cfg::kRaysPerBlock; base < n_rays; base += gridDim.x * Cfg::kRaysPerBlock) {
+    for (uint32_t base = blockIdx.x * kRaysPerBlock; base < n_rays; base += gridDim.x * kRaysPerBlock) {
         RT_STAMP(ts_iter);
         const uint32_t wave_slot0 = base + (uint32_t)(wave * S) * 32u;
         // ---- packet culling (rt_mfma.hpp, MfCull): which quads of the chunk can this wave's 128 rays not be rejected for?  The bounds
@@ -343,30 +364,22 @@ scan_solo_kernel(SceneView sc, WaveBuffers wb, MfView mf, uint32_t bounce, uint3
             c_culled += (unsigned long long)culled * kMfQuadTris * rays_here;
         }
         if (keep == 0u) {                                      // nothing of this chunk can be hit by this wave's rays: next ray block
+            if constexpr (W == 1) {
 #pragma unroll
-            for (int s = 0; s < S; ++s) { nxt_a[s] = nx2_a[s]; nxt_b[s] = nx2_b[s]; }
-            fetch_rays(base + 2u * kStride, nx2_a, nx2_b);
+                for (int s = 0; s < S; ++s) { nxt_a[s] = nx2_a[s]; nxt_b[s] = nx2_b[s]; }
+                fetch_rays(base + 2u * kStride, nx2_a, nx2_b);
+            }
             continue;
         }
         MfRay ray[S];
+        if constexpr (W == 1) {
 #pragma unroll
-        for (int s = 0; s < S; ++s) {
-            const uint32_t slot = base + (uint32_t)(wave * S + s) * 32u + (uint32_t)col;
-            MfRay &r = ray[s];
-            r.valid = slot < n_rays;
-            r.o = mk(nxt_a[s].x, nxt_a[s].y, nxt_a[s].z); r.d = mk(nxt_a[s].w, nxt_b[s].x, nxt_b[s].y);
-            r.wd = __builtin_amdgcn_sqrtf(dot3(r.d, r.d)) * 1.001f;               // (1 ulp square roots: these are bounds, inflated by 1.001)
-            r.wod = (__builtin_amdgcn_sqrtf(dot3(r.o, r.o)) * 1.001f) * r.wd;
-            const uint32_t dxy = pack_bf16(r.d.x, r.d.y);
-            r.dyz = pack_bf16(r.d.y, r.d.z);
-            r.dx_hi = dxy << 16;
-            const f3 dl = mk(r.d.x - __uint_as_float(dxy << 16), r.d.y - __uint_as_float(dxy & 0xffff0000u), r.d.z - __uint_as_float(r.dyz & 0xffff0000u));
-            r.tail = half ? pack_bf16(dl.y, dl.z) : pack_bf16(1.0f, dl.x);
+            for (int s = 0; s < S; ++s) prepare_ray(ray[s], nxt_a[s], nxt_b[s], base + (uint32_t)(wave * S + s) * 32u + (uint32_t)col < n_rays);
+            // the next blocks' rays travel while this one is scanned (one wave per SIMD: nothing else would hide the round trip)
+#pragma unroll
+            for (int s = 0; s < S; ++s) { nxt_a[s] = nx2_a[s]; nxt_b[s] = nx2_b[s]; }
+            fetch_rays(base + 2u * kStride, nx2_a, nx2_b);
         }
-        // the next blocks' rays travel while this one is scanned (one wave per SIMD: nothing else would hide the round trip)
-#pragma unroll
-        for (int s = 0; s < S; ++s) { nxt_a[s] = nx2_a[s]; nxt_b[s] = nx2_b[s]; }
-        fetch_rays(base + 2u * kStride, nx2_a, nx2_b);
 
         uint32_t qn = 0;                                        // wave-uniform
         auto flush = [&]() {
@@ -435,6 +448,11 @@ scan_solo_kernel(SceneView sc, WaveBuffers wb, MfView mf, uint32_t bounce, uint3
             const uint32_t qa = ts0 / kMfQuadTiles, nq = (ts1 - ts0) / kMfQuadTiles;
             uint32_t seg = keep & ((nq >= 32u ? 0xFFFFFFFFu : ((1u << nq) - 1u)) << qa);
             if (seg == 0u) { ts0 = ts1; continue; }
+            if constexpr (W == 2) {                              // nothing ray-related stays live across the tile loop: re-read the queue here
+                fetch_rays(base, nxt_a, nxt_b);
+#pragma unroll
+                for (int s = 0; s < S; ++s) prepare_ray(ray[s], nxt_a[s], nxt_b[s], base + (uint32_t)(wave * S + s) * 32u + (uint32_t)col < n_rays);
+            }
             const ConstFloats gp = groups_k + (size_t)g * (sizeof(MfGroup) / 4);
             MfGroup G;
             G.cx = gp[0]; G.cy = gp[1]; G.cz = gp[2]; G.E = gp[3]; G.Ml = gp[4]; G.Pw = gp[5]; G.P = gp[6]; G.pad1 = 0.0f;

@@ -207,7 +207,7 @@ struct rtgl_context {
     bool tris_dirty = false, visits_dirty = false;
     FrameParams params{};
     bool have_params = false;
-    int opt_kernel = RTGL_KERNEL_WAVEFRONT_MFMA_SOLO, opt_rng_state = 0, opt_counters = 0, opt_kernel_timing = 0, opt_wf_rays = 4, opt_wf_mode = kLds, opt_wf_chunk = 256, opt_wf_early = 0, opt_wf_packed = 0, opt_mf_chunk_quads = 32, opt_mf_group_quads = 32, opt_cull = 1, opt_debug_skip_exact = 0;
+    int opt_kernel = RTGL_KERNEL_WAVEFRONT_MFMA_SOLO, opt_rng_state = 0, opt_counters = 0, opt_kernel_timing = 0, opt_wf_rays = 4, opt_wf_mode = kLds, opt_wf_chunk = 256, opt_wf_early = 0, opt_wf_packed = 0, opt_mf_chunk_quads = 32, opt_mf_group_quads = 32, opt_cull = 1, opt_scan_waves = 0, opt_debug_skip_exact = 0;
 };
 
 static int fail(rtgl_context *ctx, int code, const std::string &msg)
@@ -269,6 +269,7 @@ extern "C" int rtgl_create_tiled(rtgl_context **out, int width, int height, int 
 #undef CCHK
     // operational override of the default scan without touching the caller: RTGL_AMD_KERNEL=0, 1, 2 or 4 (rtgl_set_option still wins)
     if (const char *k = getenv("RTGL_AMD_KERNEL")) { const int v = atoi(k); if (v >= RTGL_KERNEL_MEGA && v <= RTGL_KERNEL_WAVEFRONT_MFMA_SOLO && v != RTGL_KERNEL_REMOVED_3) { ctx->opt_kernel = v; ctx->kernel_explicit = true; } }
+    if (const char *k = getenv("RTGL_AMD_SCAN_WAVES")) { const int v = atoi(k); if (v >= 0 && v <= 2) ctx->opt_scan_waves = v; }   // A/B of the scan's occupancy
     *out = ctx;
     return RTGL_OK;
 }
@@ -611,7 +612,7 @@ static void kev_mark(rtgl_context *ctx)
 // ---- bounce-wavefront pipeline: buffers + launches ------------------------------------------------
 // kernel 4 launches at most max(CUs, chunks) blocks of four waves; each wave owns one region of the candidate buffer
 static uint32_t solo_chunks(const rtgl_context *ctx);
-static uint32_t solo_regions(const rtgl_context *ctx) { return std::max<uint32_t>((uint32_t)ctx->n_cus, solo_chunks(ctx)) * 4u; }
+static uint32_t solo_regions(const rtgl_context *ctx) { return std::max<uint32_t>((uint32_t)ctx->n_cus, solo_chunks(ctx)) * 8u; }   // (8 waves per block with two waves per SIMD)
 
 static size_t counts_bytes(uint32_t capacity) { return (size_t)(capacity + 1u) * sizeof(uint32_t); }      // ray counts per bounce + the fullest candidate region
 
@@ -723,7 +724,15 @@ static int launch_intersect_solo(rtgl_context *ctx, const SceneView &sc, uint32_
     const uint32_t gq = ctx->mf_group_quads, n_quads = ctx->n_mf_groups * gq;
     const uint32_t real_quads = std::min(n_quads, (ctx->n_tri_visits + (uint32_t)kMfQuadTris - 1) / (uint32_t)kMfQuadTris);
     using Cfg = SoloCfg;
-    const uint32_t est = estimate_rays(ctx, n0, bounce), blocks_x_all = (est + Cfg::kRaysPerBlock - 1u) / Cfg::kRaysPerBlock;
+    // Two waves per SIMD run the steady stream 1.5x faster (47 against 70 cycles per product), but a block then takes 1,024 rays per
+    // trip: a bounce with fewer than four (ray block x chunk) items per CU is better off with one wave per SIMD and 512-ray blocks
+    // (measured on C2: from ~130k rays down).  "scan_waves" = 0 chooses per launch, 1 / 2 force.
+    const uint32_t est = estimate_rays(ctx, n0, bounce);
+    const uint32_t base_chunks = (real_quads + std::min((uint32_t)ctx->opt_mf_chunk_quads, std::max(real_quads, 1u)) - 1) / std::min((uint32_t)ctx->opt_mf_chunk_quads, std::max(real_quads, 1u));
+    const uint32_t W = ctx->opt_scan_waves ? (uint32_t)ctx->opt_scan_waves
+                                           : (((uint64_t)((est + 8u * Cfg::kRaysPerWave - 1u) / (8u * Cfg::kRaysPerWave)) * base_chunks >= 4ull * (uint32_t)ctx->n_cus) ? 2u : 1u);
+    const uint32_t waves = 4u * W, rays_per_block = waves * Cfg::kRaysPerWave;
+    const uint32_t blocks_x_all = (est + rays_per_block - 1u) / rays_per_block;
     // A launch has (ray blocks x chunks) work items for one block per CU.  Late bounces (and every bounce of a rank that owns an
     // eighth of the image) have few ray blocks: cut the triangle range finer, down to 4 quads per chunk, until there are two items
     // per CU (each item pays its ray and group set-up again, ~20 % at 8 quads, so only as far as needed; never more chunks than CUs:
@@ -743,8 +752,8 @@ static int launch_intersect_solo(rtgl_context *ctx, const SceneView &sc, uint32_
     if (!ctx->solo_attr_set) {
         // allow the whole LDS of a CU (160 KB) minus the kernel's static share as dynamic shared memory.  The attribute belongs to the
         // (function, device) pair, so it is raised once per context -- a context is bound to one device -- not once per process.
-        for (const void *fn : {reinterpret_cast<const void *>(&scan_solo_kernel<false>),
-                               reinterpret_cast<const void *>(&scan_solo_kernel<true>)}) {
+        for (const void *fn : {reinterpret_cast<const void *>(&scan_solo_kernel<false, 1>), reinterpret_cast<const void *>(&scan_solo_kernel<true, 1>),
+                               reinterpret_cast<const void *>(&scan_solo_kernel<false, 2>), reinterpret_cast<const void *>(&scan_solo_kernel<true, 2>)}) {
             hipFuncAttributes fattr;
             HIPCHK(ctx, hipFuncGetAttributes(&fattr, fn));
             HIPCHK(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024 - fattr.sharedSizeBytes)));
@@ -758,12 +767,12 @@ static int launch_intersect_solo(rtgl_context *ctx, const SceneView &sc, uint32_
         const uint32_t gran = (est + 127u) / 128u;
         hipLaunchKernelGGL(packet_bounds_kernel, dim3(std::max(1u, std::min((gran + 3u) / 4u, 4096u))), dim3(256), 0, ctx->stream, ctx->wb, bounce);
     }
-    if (ctx->opt_counters)
-        hipLaunchKernelGGL((scan_solo_kernel<true>), grid, dim3(256), lds, ctx->stream, sc, ctx->wb, mf, bounce, chunk_quads, ctx->d_counters, ctx->opt_debug_skip_exact, cull);
-    else
-        hipLaunchKernelGGL((scan_solo_kernel<false>), grid, dim3(256), lds, ctx->stream, sc, ctx->wb, mf, bounce, chunk_quads, ctx->d_counters, ctx->opt_debug_skip_exact, cull);
+#define RTGL_LAUNCH_SCAN(C, WW) hipLaunchKernelGGL((scan_solo_kernel<C, WW>), grid, dim3(256 * WW), lds, ctx->stream, sc, ctx->wb, mf, bounce, chunk_quads, ctx->d_counters, ctx->opt_debug_skip_exact, cull)
+    if (W == 2) { if (ctx->opt_counters) RTGL_LAUNCH_SCAN(true, 2); else RTGL_LAUNCH_SCAN(false, 2); }
+    else { if (ctx->opt_counters) RTGL_LAUNCH_SCAN(true, 1); else RTGL_LAUNCH_SCAN(false, 1); }
+#undef RTGL_LAUNCH_SCAN
     HIPCHK(ctx, hipGetLastError());
-    hipLaunchKernelGGL(narrow_phase_kernel, dim3(blocks_x * chunks * 4u), dim3(256), 0, ctx->stream, sc, ctx->wb, mf, bounce, blocks_x * chunks * 4u);
+    hipLaunchKernelGGL(narrow_phase_kernel, dim3(blocks_x * chunks * waves), dim3(256), 0, ctx->stream, sc, ctx->wb, mf, bounce, blocks_x * chunks * waves);
     return RTGL_OK;
 }
 
@@ -1135,6 +1144,9 @@ extern "C" int rtgl_set_option(rtgl_context *ctx, const char *key, int value)
     } else if (!strcmp(key, "mf_chunk_quads")) {
         if (value < 1 || (uint32_t)value > kMfMaxChunkQuads) return fail(ctx, RTGL_ERR_INVALID, "mf_chunk_quads must be in [1, 32]");
         ctx->opt_mf_chunk_quads = value;
+    } else if (!strcmp(key, "scan_waves")) {
+        if (value < 0 || value > 2) return fail(ctx, RTGL_ERR_INVALID, "scan_waves (waves per SIMD of the kernel-4 scan) must be 0 (chosen per launch), 1 or 2");
+        ctx->opt_scan_waves = value;
     } else if (!strcmp(key, "cull")) {
         if (value < 0 || value > 2) return fail(ctx, RTGL_ERR_INVALID, "cull must be 0 (off), 1 (camera rays) or 2 (every bounce)");
         ctx->opt_cull = value;
@@ -1176,6 +1188,7 @@ extern "C" int rtgl_get_option(rtgl_context *ctx, const char *key, int *value)
     else if (!strcmp(key, "mf_chunk_quads")) *value = ctx->opt_mf_chunk_quads;
     else if (!strcmp(key, "mf_group_quads")) *value = (int)ctx->mf_group_quads;
     else if (!strcmp(key, "cull")) *value = ctx->opt_cull;
+    else if (!strcmp(key, "scan_waves")) *value = ctx->opt_scan_waves;
     else if (!strcmp(key, "rng_state")) *value = ctx->opt_rng_state;
     else if (!strcmp(key, "counters")) *value = ctx->opt_counters;
     else if (!strcmp(key, "kernel_timing")) *value = ctx->opt_kernel_timing;
