@@ -30,7 +30,7 @@
 namespace rt {
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x8 __attribute__((ext_vector_type(8)));
+typedef float f32x6 __attribute__((ext_vector_type(6)));
 
 // max / min over the 32 columns of a wave whose two lane halves hold the same values: four DPP steps inside each row of 16 lanes,
 // then the two rows through scalar registers (ds_bpermute-based shuffles cost an LDS round trip per step: 14 reductions of them
@@ -62,11 +62,14 @@ template <bool kMax> __device__ __forceinline__ float full_reduce(float x)
     return op(op(rl(0), rl(16)), op(rl(32), rl(48)));
 }
 
-// ---- packet bounds: for every granule of 128 consecutive rays of a queue (= the rays one scan wave handles per trip) an origin
-// sphere (O, ro), a direction cone (unit D, sigma = max |d^ - D|) and On >= max |o|.  One wave per granule, two rays per lane.
-// record: [O.xyz, ro] [D.xyz, sigma] [On, usable, 0, 0]; usable = 0 when a ray has a non-finite origin or a direction that cannot
-// be normalised, or when the directions spread too widely to have an axis: the scan then culls nothing for that granule.
-__global__ void __launch_bounds__(256) packet_bounds_kernel(WaveBuffers wb, uint32_t bounce)
+// ---- packet culling (rt_mfma.hpp, MfCull): for every granule of 128 consecutive rays of a queue (= the rays one scan wave handles
+// per trip) an origin sphere (O, ro), a direction cone (unit D, sigma = max |d^ - D|) and On >= max |o|, then the certificate against
+// every quad of the mesh: bit q of the granule's row of wb.keep is CLEAR when all 128 rays are certified rejections for all 40
+// triangles of quad q.  One wave per granule, two rays per lane for the bounds, one quad per lane for the test.  A granule with a
+// non-finite origin, a direction that cannot be normalised, or directions spread too widely to have an axis keeps every quad.
+// (Round 2 first evaluated the certificate inside the scan, per (wave, chunk) item: ~5,000 cycles per item for a scalar load of the
+// bounds, a conflict-ridden LDS read of the chunk's records and the test itself, 40 % of the camera-ray bounce.)
+__global__ void __launch_bounds__(256) packet_cull_kernel(WaveBuffers wb, const MfCull *__restrict__ cull, uint32_t n_quads, uint32_t bounce)
 {
     const uint32_t n_rays = wb.counts[bounce];
     const RayQueue qin = (bounce & 1u) ? wb.q[1] : wb.q[0];
@@ -108,10 +111,37 @@ __global__ void __launch_bounds__(256) packet_bounds_kernel(WaveBuffers wb, uint
         ro = full_reduce<true>(ro) * 1.0001f + 1e-30f; sigma = full_reduce<true>(sigma) * 1.0001f + 2e-6f;
         usable = !__any(!usable) && (Dl > 0.25f);
         const float On = __builtin_amdgcn_sqrtf(dot3(O, O)) * 1.0001f + ro;
-        if (lane == 0u) {
-            wb.packets[3 * (size_t)g + 0] = make_float4(O.x, O.y, O.z, ro);
-            wb.packets[3 * (size_t)g + 1] = make_float4(D.x, D.y, D.z, sigma);
-            wb.packets[3 * (size_t)g + 2] = make_float4(On, usable ? 1.0f : 0.0f, 0.0f, 0.0f);
+        uint32_t *const row = wb.keep + (size_t)g * wb.keep_words;
+        // (the record of the next pass travels while this one is evaluated)
+        MfCull c_next = {};
+        bool have_next = usable && lane < n_quads;
+        if (have_next) c_next = cull[lane];
+        for (uint32_t q0 = 0; q0 < n_quads; q0 += 64u) {
+            const MfCull c = c_next;
+            const bool have_this = have_next;
+            have_next = usable && q0 + 64u + lane < n_quads;
+            if (have_next) c_next = cull[q0 + 64u + lane];
+            bool skip = false;
+            if (have_this) {
+                const f3 w = mk(c.cx, c.cy, c.cz) - O;
+                const float L = __builtin_amdgcn_sqrtf(dot3(w, w)) * 1.0001f;
+                const f3 cr = cross3(w, D);
+                const float crn = __builtin_amdgcn_sqrtf(dot3(cr, cr));
+                const float delta = (crn * 0.9999f - L * sigma) - (ro + c.R) - 1e-5f * (L + ro + c.R);      // the lines miss the sphere by at least this
+                // range of D.n^ over the box of the quad's unit normals; |d^.n^ - D.n^| <= sigma
+                const float plo = (fminf(D.x * c.nlx, D.x * c.nhx) + fminf(D.y * c.nly, D.y * c.nhy)) + fminf(D.z * c.nlz, D.z * c.nhz);
+                const float phi = (fmaxf(D.x * c.nlx, D.x * c.nhx) + fmaxf(D.y * c.nly, D.y * c.nhy)) + fmaxf(D.z * c.nlz, D.z * c.nhz);
+                const float cmin = ((plo > 0.0f) ? plo : ((phi < 0.0f) ? -phi : -1.0f)) - sigma - 1e-5f;
+                const float lhs = (c.Nmin * cmin) * fminf(0.3333f, delta * c.shape) * 0.99f;
+                const float rhs = 9.5367431640625e-07f * __builtin_fmaf(c.E, On, c.Pw) * 1.01f;      // 2^-20 (E |o| + Pw): the reference's own rounding (mf_margin)
+                skip = (delta > 0.0f) && (cmin > 0.0f) && (c.Nmin > 0.0f) && (lhs > 0.0f) && (lhs >= rhs);    // any NaN: false
+            }
+            const unsigned long long have = (n_quads - q0 >= 64u) ? ~0ull : ((1ull << (n_quads - q0)) - 1ull);
+            const unsigned long long keep = ~(unsigned long long)__builtin_amdgcn_ballot_w64(skip) & have;
+            if (lane == 0u) {
+                row[q0 >> 5] = (uint32_t)keep;
+                if ((q0 >> 5) + 1u < wb.keep_words) row[(q0 >> 5) + 1u] = (uint32_t)(keep >> 32);
+            }
         }
     }
 }
@@ -129,8 +159,8 @@ struct SoloCfg {
 // the examination reads has to sit there):
 //     X0..X3 = v[128:143] v[144:159] v[160:175] v[176:191]      accumulators of the tile in flight / pending, by ray set
 //     Y0..Y3 = v[192:207] v[208:223] v[224:239] v[240:255]
-//     MA0..3 = v[96:103] v[104:111] v[112:119] v[120:127]       minima (5 per set, slot 5 = their maximum) written by a Y stage
-//     MB0..3 = v[64:71]  v[72:79]   v[80:87]   v[88:95]         ... by an X stage
+//     MA0..3 = v[96:101] v[104:109] v[112:117] v[120:125]       minima (5 per set, slot 5 = their maximum) written by a Y stage
+//     MB0..3 = v[64:69]  v[72:77]   v[80:85]   v[88:93]         ... by an X stage   (the two registers behind each block are the compiler's)
 //     KA = s[36:43], KB = s[44:51]                              "lanes with a survivor" per ray set of the first / second stage of a trip
 //                                                               (s32..s34 are the ABI's stack / frame registers: kept clear of)
 // The blocks are bound with physical-register constraints, so the compiler sees ordinary dataflow (it keeps its own values out of
@@ -171,8 +201,8 @@ struct SoloCfg {
     asm volatile(RT_STAGE_Y_TEXT("%[ay]") RT_STAGE_X_TEXT("%[ax]") RT_FOLD("%[anya]", 36) RT_FOLD("%[anyb]", 44) \
                  : "+{v[128:143]}"(X0), "+{v[144:159]}"(X1), "+{v[160:175]}"(X2), "+{v[176:191]}"(X3), \
                    "=&{v[192:207]}"(Y0), "=&{v[208:223]}"(Y1), "=&{v[224:239]}"(Y2), "=&{v[240:255]}"(Y3), \
-                   "=&{v[96:103]}"(MA0), "=&{v[104:111]}"(MA1), "=&{v[112:119]}"(MA2), "=&{v[120:127]}"(MA3), \
-                   "=&{v[64:71]}"(MB0), "=&{v[72:79]}"(MB1), "=&{v[80:87]}"(MB2), "=&{v[88:95]}"(MB3), [anya] "=&s"(any_a), [anyb] "=&s"(any_b) \
+                   "=&{v[96:101]}"(MA0), "=&{v[104:109]}"(MA1), "=&{v[112:117]}"(MA2), "=&{v[120:125]}"(MA3), \
+                   "=&{v[64:69]}"(MB0), "=&{v[72:77]}"(MB1), "=&{v[80:85]}"(MB2), "=&{v[88:93]}"(MB3), [anya] "=&s"(any_a), [anyb] "=&s"(any_b) \
                  : [ay] "v"(AY), [ax] "v"(AX), [b0] "v"(B0), [b1] "v"(B1), [b2] "v"(B2), [b3] "v"(B3), [t0] "v"(th0), [t1] "v"(th1), [t2] "v"(th2), [t3] "v"(th3) \
                  : RT_K_CLOBBERS)
 // the same trip, which also issues the LDS reads of the tile rows two trips ahead (into NY, NX; `addr` = LDS byte address of the
@@ -185,8 +215,8 @@ struct SoloCfg {
                  RT_STAGE_X_TEXT("%[ax]") "s_waitcnt lgkmcnt(0)\n\t" RT_FOLD("%[anya]", 36) RT_FOLD("%[anyb]", 44) \
                  : "+{v[128:143]}"(X0), "+{v[144:159]}"(X1), "+{v[160:175]}"(X2), "+{v[176:191]}"(X3), \
                    "=&{v[192:207]}"(Y0), "=&{v[208:223]}"(Y1), "=&{v[224:239]}"(Y2), "=&{v[240:255]}"(Y3), \
-                   "=&{v[96:103]}"(MA0), "=&{v[104:111]}"(MA1), "=&{v[112:119]}"(MA2), "=&{v[120:127]}"(MA3), \
-                   "=&{v[64:71]}"(MB0), "=&{v[72:79]}"(MB1), "=&{v[80:87]}"(MB2), "=&{v[88:95]}"(MB3), [anya] "=&s"(any_a), [anyb] "=&s"(any_b), \
+                   "=&{v[96:101]}"(MA0), "=&{v[104:109]}"(MA1), "=&{v[112:117]}"(MA2), "=&{v[120:125]}"(MA3), \
+                   "=&{v[64:69]}"(MB0), "=&{v[72:77]}"(MB1), "=&{v[80:85]}"(MB2), "=&{v[88:93]}"(MB3), [anya] "=&s"(any_a), [anyb] "=&s"(any_b), \
                    [ny] "=&v"(NY), [nx] "=&v"(NX), [addr] "+v"(ADDR) \
                  : [ay] "v"(AY), [ax] "v"(AX), [b0] "v"(B0), [b1] "v"(B1), [b2] "v"(B2), [b3] "v"(B3), [t0] "v"(th0), [t1] "v"(th1), [t2] "v"(th2), [t3] "v"(th3) \
                  : RT_K_CLOBBERS, "memory")
@@ -195,7 +225,7 @@ struct SoloCfg {
 #define RT_STAGE_Y(AY) \
     asm volatile(RT_STAGE_Y_TEXT("%[ay]") RT_FOLD("%[anya]", 36) \
                  : "=&{v[192:207]}"(Y0), "=&{v[208:223]}"(Y1), "=&{v[224:239]}"(Y2), "=&{v[240:255]}"(Y3), \
-                   "=&{v[96:103]}"(MA0), "=&{v[104:111]}"(MA1), "=&{v[112:119]}"(MA2), "=&{v[120:127]}"(MA3), [anya] "=&s"(any_a) \
+                   "=&{v[96:101]}"(MA0), "=&{v[104:109]}"(MA1), "=&{v[112:117]}"(MA2), "=&{v[120:125]}"(MA3), [anya] "=&s"(any_a) \
                  : "{v[128:143]}"(X0), "{v[144:159]}"(X1), "{v[160:175]}"(X2), "{v[176:191]}"(X3), \
                    [ay] "v"(AY), [b0] "v"(B0), [b1] "v"(B1), [b2] "v"(B2), [b3] "v"(B3), [t0] "v"(th0), [t1] "v"(th1), [t2] "v"(th2), [t3] "v"(th3) \
                  : RT_K_CLOBBERS)
@@ -205,12 +235,12 @@ struct SoloCfg {
                  : [a] "v"(AOP), [b0] "v"(B0), [b1] "v"(B1), [b2] "v"(B2), [b3] "v"(B3))
 #define RT_EXAMINE_X() \
     asm volatile("s_nop 15\n\t" RT_EXAM(128, 96, 36, "%[t0]") RT_EXAM(144, 104, 38, "%[t1]") RT_EXAM(160, 112, 40, "%[t2]") RT_EXAM(176, 120, 42, "%[t3]") "s_nop 7" \
-                 : "=&{v[96:103]}"(MA0), "=&{v[104:111]}"(MA1), "=&{v[112:119]}"(MA2), "=&{v[120:127]}"(MA3) \
+                 : "=&{v[96:101]}"(MA0), "=&{v[104:109]}"(MA1), "=&{v[112:117]}"(MA2), "=&{v[120:125]}"(MA3) \
                  : "{v[128:143]}"(X0), "{v[144:159]}"(X1), "{v[160:175]}"(X2), "{v[176:191]}"(X3), [t0] "v"(th0), [t1] "v"(th1), [t2] "v"(th2), [t3] "v"(th3) \
                  : RT_K_CLOBBERS)
 #define RT_EXAMINE_Y() \
     asm volatile("s_nop 15\n\t" RT_EXAM(192, 64, 44, "%[t0]") RT_EXAM(208, 72, 46, "%[t1]") RT_EXAM(224, 80, 48, "%[t2]") RT_EXAM(240, 88, 50, "%[t3]") "s_nop 7" \
-                 : "=&{v[64:71]}"(MB0), "=&{v[72:79]}"(MB1), "=&{v[80:87]}"(MB2), "=&{v[88:95]}"(MB3) \
+                 : "=&{v[64:69]}"(MB0), "=&{v[72:77]}"(MB1), "=&{v[80:85]}"(MB2), "=&{v[88:93]}"(MB3) \
                  : "{v[192:207]}"(Y0), "{v[208:223]}"(Y1), "{v[224:239]}"(Y2), "{v[240:255]}"(Y3), [t0] "v"(th0), [t1] "v"(th1), [t2] "v"(th2), [t3] "v"(th3) \
                  : RT_K_CLOBBERS)
 
@@ -220,100 +250,134 @@ struct SoloCfg {
 #define RT_MASK_SET(ML, TH) RT_MASK_BIT(ML, 4, TH) RT_MASK_BIT(ML, 3, TH) RT_MASK_BIT(ML, 2, TH) RT_MASK_BIT(ML, 1, TH) RT_MASK_BIT(ML, 0, TH)
 #define RT_MASK_A(MASK) \
     asm volatile("v_mov_b32_e32 %[m], 0\n\t" RT_MASK_SET(120, "%[t3]") RT_MASK_SET(112, "%[t2]") RT_MASK_SET(104, "%[t1]") RT_MASK_SET(96, "%[t0]") \
-                 : [m] "=&v"(MASK) : "{v[96:103]}"(MA0), "{v[104:111]}"(MA1), "{v[112:119]}"(MA2), "{v[120:127]}"(MA3), \
+                 : [m] "=&v"(MASK) : "{v[96:101]}"(MA0), "{v[104:109]}"(MA1), "{v[112:117]}"(MA2), "{v[120:125]}"(MA3), \
                    [t0] "v"(th0), [t1] "v"(th1), [t2] "v"(th2), [t3] "v"(th3) : "vcc")
 #define RT_MASK_B(MASK) \
     asm volatile("v_mov_b32_e32 %[m], 0\n\t" RT_MASK_SET(88, "%[t3]") RT_MASK_SET(80, "%[t2]") RT_MASK_SET(72, "%[t1]") RT_MASK_SET(64, "%[t0]") \
-                 : [m] "=&v"(MASK) : "{v[64:71]}"(MB0), "{v[72:79]}"(MB1), "{v[80:87]}"(MB2), "{v[88:95]}"(MB3), \
+                 : [m] "=&v"(MASK) : "{v[64:69]}"(MB0), "{v[72:77]}"(MB1), "{v[80:85]}"(MB2), "{v[88:93]}"(MB3), \
                    [t0] "v"(th0), [t1] "v"(th1), [t2] "v"(th2), [t3] "v"(th3) : "vcc")
 
 // diagnostics build (-DRT_SOLO_STAMPS): s_memtime stamps around the phases of a wave's life, summed into mf.dbg_log
-#ifdef RT_SOLO_STAMPS
+// (-DRT_SOLO_STAMPS=2: only the begin and the end of every wave, on the constant 100 MHz clock: mean and slowest wave per bounce in units
+// of 10 ns, to set against the launch durations of a profile -- what the distribution of work over the waves loses)
+#if defined(RT_SOLO_STAMPS) && RT_SOLO_STAMPS == 2
+#define RT_STAMP(var) const unsigned long long var = 0
+#define RT_STAMP_ADD(acc, from, to)
+#define RT_STAMP_NOW() __builtin_amdgcn_s_memrealtime()
+#elif defined(RT_SOLO_STAMPS)
 #define RT_STAMP(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
 #define RT_STAMP_ADD(acc, from, to) acc += (to) - (from)
+#define RT_STAMP_NOW() __builtin_amdgcn_s_memtime()
 #else
 #define RT_STAMP(var)
 #define RT_STAMP_ADD(acc, from, to)
 #endif
 
-// W = waves per SIMD.  W = 1: the wave owns the register file (256 + AGPRs) and hides its own latencies (rays of the next two
-// trips in flight).  W = 2: two waves share a SIMD, 256 registers each; a wave alone can issue one vector instruction per 4 cycles
+// ---- culled bounces: the work items of a scan launch.  For every chunk of `chunk_quads` quads the granules whose keep bits are not all
+// clear, as (granule, keep bits of the chunk), compacted (one atomic per 64 granules; the order inside a chunk's list is whatever the
+// atomics made it: it only decides which wave scans what).  Granules with nothing to scan never become an item: with 95 % of the
+// camera rays' tests culled two thirds of the (granule, chunk) pairs of C2 are empty.  grid = (ceil(granules / 256), chunks).
+template <bool kCount>
+__global__ void __launch_bounds__(256) cull_items_kernel(WaveBuffers wb, uint32_t bounce, uint32_t chunk_quads, uint32_t n_quads, Counters *__restrict__ counters)
+{
+    const uint32_t n_rays = wb.counts[bounce], n_gran = (n_rays + 127u) >> 7;
+    const uint32_t c = blockIdx.y, q_begin = c * chunk_quads, q_end = min(q_begin + chunk_quads, n_quads);
+    const uint32_t lane = threadIdx.x & 63u;
+    if (q_begin >= q_end) return;
+    unsigned long long culled = 0;
+    for (uint32_t g0 = blockIdx.x * 256u + (threadIdx.x & ~63u); g0 < n_gran; g0 += gridDim.x * 256u) {      // (wave-uniform bound)
+        const uint32_t g = g0 + lane;
+        uint32_t bits = 0u;
+        if (g < n_gran) {
+            const uint32_t *w = wb.keep + ((size_t)g * wb.keep_words + (q_begin >> 5));
+            const unsigned long long two = (unsigned long long)w[0] | ((unsigned long long)w[1] << 32);    // (the second word may lie behind the row: masked out)
+            bits = (uint32_t)(two >> (q_begin & 31u)) & (0xFFFFFFFFu >> (32u - (q_end - q_begin)));
+            if (kCount) culled += (unsigned long long)((q_end - q_begin) - (uint32_t)__popc(bits)) * kMfQuadTris * min(128u, n_rays - g * 128u);
+        }
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(bits != 0u);
+        if (m == 0ull) continue;
+        uint32_t at = 0u;
+        if (lane == 0u) at = atomicAdd(wb.item_counts + c, (uint32_t)__popcll(m));
+        at = __builtin_amdgcn_readfirstlane(at) + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+        if (bits != 0u) wb.items[(size_t)c * wb.items_stride + at] = make_uint2(g, bits);
+    }
+    if (kCount && culled) atomicAdd(&counters->culled_tests, culled);
+}
+
+// W = waves per SIMD.  W = 1: the wave owns the register file (256 + AGPRs) and hides its own latencies (the rays of its next item
+// travel while it scans).  W = 2: two waves share a SIMD, 256 registers each; a wave alone can issue one vector instruction per 4 cycles
 // while the SIMD executes one per 2, so the second wave's VALU work runs beside the first one's and the stream becomes bound by
 // the matrix pipe itself (tools/scan_stage_rate.hip: 33 cycles per product against 46); the second wave also fills the holes that
 // scalar instructions, branches and the parking path tear into the stream.  The W = 2 form keeps nothing ray-related live across
 // the tile loop (rays are re-read from the queue at every segment: the partner wave hides the round trip).
+//
+// Work distribution.  A work item = (granule of 128 rays, chunk of <= 32 quads whose A tiles sit in LDS).  A block starts on chunk
+// blockIdx.x mod n_chunks.
+//   * static (`dynamic` = 0): the block stays there; its waves and those of the other blocks of the chunk take the chunk's items in
+//     turn (wave r of n takes items r, r + n, ...).  Nothing is synchronised, every wave knows its next item (whose record and rays
+//     travel while it scans).  Best when the chunks cost about the same and there are many blocks per chunk: C2, C5.
+//   * dynamic (`dynamic` = 1): the waves CLAIM the chunk's items from a counter in global memory (sched[chunk]), in batches, each at
+//     its own pace; when the chunk has no unclaimed item left the block moves on, cyclically, to the next chunk that has, stages its
+//     tiles and carries on there, until no chunk has.  Costs a round trip per batch and a block-wide wait per move; pays when
+//     a launch has few blocks per chunk and the chunks differ (C4: 79 chunks for 256 CUs, camera rays culled for some chunks and not
+//     for others: the static launch lasted 1.33x its mean wave; dynamic: 29.9 -> 33.9 Mpaths/s.  On C2 the static form is 14 %
+//     faster: 8 chunks, 32 blocks each).
 template <bool kCount, int W>
 __global__ void __launch_bounds__(256 * W) __attribute__((amdgpu_waves_per_eu(W, W)))
-scan_solo_kernel(SceneView sc, WaveBuffers wb, MfView mf, uint32_t bounce, uint32_t chunk_quads, Counters *__restrict__ counters, int debug_skip_exact, int cull)
+scan_solo_kernel(SceneView sc, WaveBuffers wb, MfView mf, uint32_t bounce, uint32_t chunk_quads, uint32_t n_chunks, Counters *__restrict__ counters, int debug_skip_exact, int cull, int dynamic)
 {
     using Cfg = SoloCfg;
     constexpr int S = kSoloSets;
-    constexpr uint32_t kWaves = 4u * (uint32_t)W, kThreads = 256u * (uint32_t)W, kRaysPerBlock = kWaves * Cfg::kRaysPerWave;
+    constexpr uint32_t kWaves = 4u * (uint32_t)W, kThreads = 256u * (uint32_t)W;
     extern __shared__ uint4 lds_tiles[];                      // the chunk's A tiles, [quad][tile][panel][row]
     __shared__ uint2 lds_queue[kWaves * Cfg::kQueue];        // per-wave survivor queue, entry = (lane | tile in chunk << 8, 20-bit mask: bit 5 s + u = triangle u of the lane's half survived for ray set s)
-    RT_STAMP(ts_begin);
+    __shared__ uint32_t lds_pick;                             // the chunk the block scans next
 #ifdef RT_SOLO_STAMPS
-    unsigned long long tt_stage = 0, tt_rays = 0, tt_group = 0, tt_steady = 0, tt_park = 0, tt_flush = 0, tt_iters = 0;
+    const unsigned long long ts_wave_begin = RT_STAMP_NOW();
+    unsigned long long tt_stage = 0, tt_rays = 0, tt_group = 0, tt_steady = 0, tt_park = 0, tt_flush = 0, tt_iters = 0, tt_culled = 0, tt_culled_n = 0, tt_tiles = 0;
 #endif
-    const uint32_t n_rays = wb.counts[bounce];
+    // A wave of this kernel must have its SIMD to itself.  With one wave per SIMD the kernel needs ~340 of the SIMD's 512 registers, and
+    // waves of OTHER kernels (another context's shading, ray generation ...) used to move in beside it: three contexts rendering on one
+    // device then produced, in 10-40 % of the runs, 16 wrong pixels -- always queue slots 48..63 of a 64-slot block, i.e. lanes 48..63 of
+    // one wave of a lane-per-slot kernel -- while the scan's own survivor counts stayed exact (tools/diagnostics/flaky_multi.py; the
+    // fault was in every build since round 1 and is the same one that made round 1's three-waves-per-SIMD variant lose survivors).
+    // Claiming the whole register file (two waves per SIMD: 2 x 256, one wave: 512) keeps everything else off the SIMD: 0 wrong images
+    // in 240 runs.  What exactly a co-resident wave suffers is not established (tools/coresident_probe.hip does not reproduce it with
+    // synthetic victims); DESIGN.md 5.2.
+    if constexpr (W == 1) asm volatile("" ::: "a255");
+    const uint32_t n_rays = wb.counts[bounce], n_gran = (n_rays + 127u) >> 7;
     const RayQueue qin = (bounce & 1u) ? wb.q[1] : wb.q[0];
     unsigned long long *best = (bounce & 1u) ? wb.best[1] : wb.best[0];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, col = lane & 31, half = lane >> 5;
     // only quads that hold triangles; the padding rows inside the last one carry a -3e38 bias and never survive
-    const uint32_t q_begin = blockIdx.y * chunk_quads, q_end = min(q_begin + chunk_quads, min(mf.n_quads, (sc.n_tri_visits + kMfQuadTris - 1u) / kMfQuadTris));
+    const uint32_t real_quads = min(mf.n_quads, (sc.n_tri_visits + kMfQuadTris - 1u) / kMfQuadTris);
     // survivors of this wave go to ITS region of the candidate buffer: no atomic, no round trip the single wave of a SIMD would wait for
-    const uint32_t region = (blockIdx.y * gridDim.x + blockIdx.x) * kWaves + (uint32_t)wave;
+    const uint32_t region = blockIdx.x * kWaves + (uint32_t)wave;
     uint2 *const cand = wb.cand + (size_t)region * wb.cand_region;
     unsigned long long appended = 0;                           // wave-uniform; pairs beyond the region's capacity are tested in place
-    if (q_begin >= q_end) { if (lane == 0) wb.cand_counts[region] = 0u; return; }
-    const uint32_t v_chunk_begin = q_begin * kMfQuadTris, v_chunk_end = min(q_end * (uint32_t)kMfQuadTris, sc.n_tri_visits);
+    uint32_t *const sched = wb.sched + (size_t)bounce * wb.sched_stride;
+    uint32_t opaque_zero = 0u;
+    asm volatile("" : "+v"(opaque_zero));
     const uint32_t group_shift = (uint32_t)__builtin_ctz(mf.group_quads);
-    const uint32_t n_tiles = (q_end - q_begin) * kMfQuadTiles;
     constexpr uint32_t kQuadBytes = kMfQuadTiles * 1024;
-    {
-        const uint32_t n16 = (q_end - q_begin) * (kQuadBytes / 16u);
-        const uint4 *src = mf.A + (size_t)q_begin * (kQuadBytes / 16u);
-        // eight loads in flight per thread (a plain copy loop waits for every load: 32 exposed L2 round trips per launch)
-        for (uint32_t i0 = threadIdx.x; i0 < n16; i0 += 8u * kThreads) {
-            uint4 v[8];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) { const uint32_t i = i0 + (uint32_t)k * kThreads; v[k] = src[min(i, n16 - 1u)]; }
-#pragma unroll
-            for (int k = 0; k < 8; ++k) { const uint32_t i = i0 + (uint32_t)k * kThreads; if (i < n16) lds_tiles[i] = v[k]; }
-        }
-        // the chunk's cull records behind the tiles (and the two spare rows): one 64-byte record per quad
-        const uint4 *csrc = reinterpret_cast<const uint4 *>(mf.cull + q_begin);
-        uint4 *cdst = lds_tiles + (size_t)(chunk_quads * kMfQuadTiles + 4u) * 64u;
-        if (threadIdx.x < (q_end - q_begin) * 4u) cdst[threadIdx.x] = csrc[threadIdx.x];
-        __syncthreads();
-    }
-    const MfCull *lds_cull = reinterpret_cast<const MfCull *>(lds_tiles + (size_t)(chunk_quads * kMfQuadTiles + 4u) * 64u);
-    unsigned long long c_culled = 0;
-    RT_STAMP(ts_staged);
-    RT_STAMP_ADD(tt_stage, ts_begin, ts_staged);
     uint2 *queue = lds_queue + wave * Cfg::kQueue;
     unsigned long long c_cand_lane = 0;                        // kCount: surviving pairs this lane handed over
+    unsigned long long c_culled = 0;                           // kCount: ray x triangle pairs the keep bits spared this wave (static launches)
     typedef const float __attribute__((address_space(4))) *ConstFloats;       // group records: uniform index => s_load
+    typedef const uint32_t __attribute__((address_space(4))) *ConstWords;
     const ConstFloats groups_k = (ConstFloats)(uintptr_t)mf.groups;
     const uint32_t l_lane = (uint32_t)half * 32u + (uint32_t)col;              // this lane's row inside a tile (uint4 index)
 
-    // rays of one block as they sit in the queue: both lane halves hold the same ray
-    // Two ray blocks are in flight ahead of the one being scanned: with culling a camera-ray block is scanned in ~3k cycles, less
-    // than one L2 round trip of its successor's rays
-    float4 nxt_a[S], nxt_b[S], nx2_a[S], nx2_b[S];
-    auto fetch_rays = [&](uint32_t base, float4 (&da)[S], float4 (&db)[S]) {
+    // rays of one granule as they sit in the queue: both lane halves hold the same ray
+    float4 nxt_a[S], nxt_b[S];
+    auto fetch_rays = [&](uint32_t g, float4 (&da)[S], float4 (&db)[S]) {
 #pragma unroll
         for (int s = 0; s < S; ++s) {
-            const uint32_t slot = base + (uint32_t)(wave * S + s) * 32u + (uint32_t)col;
+            const uint32_t slot = g * 128u + (uint32_t)s * 32u + (uint32_t)col;
             da[s] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); db[s] = da[s];
             if (slot < n_rays) { da[s] = qin.a[slot]; db[s] = qin.b[slot]; }
         }
     };
-    const uint32_t kStride = gridDim.x * kRaysPerBlock;
-    if constexpr (W == 1) {
-        fetch_rays(blockIdx.x * kRaysPerBlock, nxt_a, nxt_b);
-        fetch_rays(blockIdx.x * kRaysPerBlock + kStride, nx2_a, nx2_b);
-    }
     // the constants of a ray over the scan, from its queue record
     auto prepare_ray = [&](MfRay &r, const float4 &a, const float4 &b, bool valid) {
         r.valid = valid;
@@ -327,59 +391,109 @@ scan_solo_kernel(SceneView sc, WaveBuffers wb, MfView mf, uint32_t bounce, uint3
         r.tail = half ? pack_bf16(dl.y, dl.z) : pack_bf16(1.0f, dl.x);
     };
 
-    for (uint32_t base = blockIdx.x * kRaysPerBlock; base < n_rays; base += gridDim.x * kRaysPerBlock) {
-        RT_STAMP(ts_iter);
-        const uint32_t wave_slot0 = base + (uint32_t)(wave * S) * 32u;
-        // ---- packet culling (rt_mfma.hpp, MfCull): which quads of the chunk can this wave's 128 rays not be rejected for?  The bounds
-        // of the wave's rays come from packet_bounds_kernel (one record per 128 rays; read through the scalar cache).
-        uint32_t keep = 0xFFFFFFFFu >> (32u - (q_end - q_begin));              // bit q: quad q of the chunk must be scanned
-        if (cull) {
-            typedef const float __attribute__((address_space(4))) *ConstRec;
-            const uint32_t gran = __builtin_amdgcn_readfirstlane((base >> 7) + (uint32_t)wave);
-            const ConstRec pk = (ConstRec)(uintptr_t)(wb.packets + 3 * (size_t)gran);
-            const f3 O = mk(pk[0], pk[1], pk[2]), D = mk(pk[4], pk[5], pk[6]);
-            const float ro = pk[3], sigma = pk[7], On = pk[8];
-            const bool usable = pk[9] != 0.0f;
-            bool skip = false;
-            if (usable && (uint32_t)lane < q_end - q_begin) {
-                const MfCull c = lds_cull[lane];
-                const f3 w = mk(c.cx, c.cy, c.cz) - O;
-                const float L = __builtin_amdgcn_sqrtf(dot3(w, w)) * 1.0001f;
-                const f3 cr = cross3(w, D);
-                const float crn = __builtin_amdgcn_sqrtf(dot3(cr, cr));
-                const float delta = (crn * 0.9999f - L * sigma) - (ro + c.R) - 1e-5f * (L + ro + c.R);      // the lines miss the sphere by at least this
-                // range of D.n^ over the box of the quad's unit normals; |d^.n^ - D.n^| <= sigma
-                const float plo = (fminf(D.x * c.nlx, D.x * c.nhx) + fminf(D.y * c.nly, D.y * c.nhy)) + fminf(D.z * c.nlz, D.z * c.nhz);
-                const float phi = (fmaxf(D.x * c.nlx, D.x * c.nhx) + fmaxf(D.y * c.nly, D.y * c.nhy)) + fmaxf(D.z * c.nlz, D.z * c.nhz);
-                const float cmin = ((plo > 0.0f) ? plo : ((phi < 0.0f) ? -phi : -1.0f)) - sigma - 1e-5f;
-                const float lhs = (c.Nmin * cmin) * fminf(0.3333f, delta * c.shape) * 0.99f;
-                const float rhs = 9.5367431640625e-07f * __builtin_fmaf(c.E, On, c.Pw) * 1.01f;      // 2^-20 (E |o| + Pw): the reference's own rounding (mf_margin)
-                skip = (delta > 0.0f) && (cmin > 0.0f) && (c.Nmin > 0.0f) && (lhs > 0.0f) && (lhs >= rhs);    // any NaN: false
+    for (uint32_t c_from = blockIdx.x % n_chunks;;) {
+        // ---- dynamic: the block picks the next chunk (cyclically from c_from) that has unclaimed items; none: done
+        RT_STAMP(ts_pick);
+        uint32_t c = c_from;
+        if (dynamic) {
+            __syncthreads();                                   // every wave is done with the tiles (and the pick) of the previous chunk
+            if (wave == 0) {
+                uint32_t dist = 0xFFFFFFFFu;
+                for (uint32_t cc = (uint32_t)lane; cc < n_chunks; cc += 64u) {
+                    const uint32_t have = cull ? wb.item_counts[cc] : n_gran;      // (this loop runs in dynamic launches only)
+                    if (__hip_atomic_load(sched + cc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < have) dist = min(dist, (cc + n_chunks - c_from) % n_chunks);
+                }
+                for (int off = 32; off > 0; off >>= 1) dist = min(dist, (uint32_t)__shfl_xor((int)dist, off));
+                if (lane == 0) lds_pick = dist == 0xFFFFFFFFu ? 0xFFFFFFFFu : (c_from + dist) % n_chunks;
             }
-            keep &= ~(uint32_t)__builtin_amdgcn_ballot_w64(skip);
+            __syncthreads();
+            c = lds_pick;
+            if (c == 0xFFFFFFFFu) break;
         }
-        if (kCount && lane == 0) {
-            const uint32_t culled = (uint32_t)__builtin_popcount(~keep & (0xFFFFFFFFu >> (32u - (q_end - q_begin))));
-            const uint32_t rays_here = wave_slot0 < n_rays ? min(128u, n_rays - wave_slot0) : 0u;
-            c_culled += (unsigned long long)culled * kMfQuadTris * rays_here;
+        c_from = (c + 1u) % n_chunks;
+        const uint32_t q_begin = c * chunk_quads, q_end = min(q_begin + chunk_quads, real_quads);
+        const uint32_t v_chunk_begin = q_begin * kMfQuadTris, v_chunk_end = min(q_end * (uint32_t)kMfQuadTris, sc.n_tri_visits);
+        const uint32_t n_tiles = (q_end - q_begin) * kMfQuadTiles;
+        const uint32_t keep_all = 0xFFFFFFFFu >> (32u - (q_end - q_begin));
+        {
+            const uint32_t n16 = (q_end - q_begin) * (kQuadBytes / 16u);
+            const uint4 *src = mf.A + (size_t)q_begin * (kQuadBytes / 16u);
+            // eight loads in flight per thread (a plain copy loop waits for every load: 32 exposed L2 round trips per staging)
+            for (uint32_t i0 = threadIdx.x; i0 < n16; i0 += 8u * kThreads) {
+                uint4 v[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { const uint32_t i = i0 + (uint32_t)k * kThreads; v[k] = src[min(i, n16 - 1u)]; }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { const uint32_t i = i0 + (uint32_t)k * kThreads; if (i < n16) lds_tiles[i] = v[k]; }
+            }
+            __syncthreads();
         }
-        if (keep == 0u) {                                      // nothing of this chunk can be hit by this wave's rays: next ray block
+        RT_STAMP(ts_staged);
+        RT_STAMP_ADD(tt_stage, ts_pick, ts_staged);
+
+        // ---- the wave's items of this chunk.  Static: item (rank of the wave among the waves that start on this chunk) + i x (their
+        // number).  Dynamic: claimed from the chunk's counter in guided batches -- a quarter of an even share of what is left, at most
+        // 16 items, at least one (a single address takes some ten million atomics per second: one claim per item and wave made the
+        // claims queue up behind each other, ~5 us each); the wave waits for a claim, once per batch.
+        uint32_t *const counter = sched + c;
+        const uint32_t n_items = __builtin_amdgcn_readfirstlane((cull && dynamic) ? wb.item_counts[c] : n_gran);
+        const ConstWords items_k = (ConstWords)(uintptr_t)(wb.items + (size_t)c * wb.items_stride);
+        const uint32_t blocks_here = (gridDim.x - c + n_chunks - 1u) / n_chunks;      // blocks that start on this chunk
+        constexpr uint32_t kNone = 0xFFFFFFFFu;
+        // (the address is made to look divergent: for a uniform one LLVM's atomic optimizer rewrites the operation into its wave-aggregated
+        // form, which is no faster here and longer)
+        auto claim = [&](uint32_t seen, uint32_t &lo, uint32_t &end) {
+            const uint32_t rem = n_items > seen ? n_items - seen : 0u;
+            const uint32_t n = min(max(rem / (4u * max(blocks_here, 1u) * kWaves), 1u), 16u);
+            uint32_t v = 0u;
+            if (lane == 0) v = atomicAdd(counter + opaque_zero, n);
+            const uint32_t at = __builtin_amdgcn_readfirstlane(v);
+            lo = min(at, n_items); end = min(at + n, n_items);
+        };
+        // item k of the chunk: the granule and which of the chunk's quads its rays cannot be rejected for (bit q: quad q must be scanned).
+        // Culled bounces: dynamic launches read the compacted list of cull_items_kernel, static ones the granule's own keep bits (the
+        // chunk's <= 32 bits sit in at most two words of the row; the second may lie behind the row: masked out, the buffer ends 16
+        // rows behind the last granule), through the scalar cache.
+        const ConstWords keep_k = (ConstWords)(uintptr_t)wb.keep;
+        auto item_of = [&](uint32_t k, uint32_t &g, uint32_t &bits) {
+            g = k; bits = keep_all;
+            if (cull) {
+                if (dynamic) { g = items_k[2u * (size_t)k]; bits = items_k[2u * (size_t)k + 1u]; }
+                else {
+                    const ConstWords w = keep_k + ((size_t)k * wb.keep_words + (q_begin >> 5));
+                    bits = (uint32_t)(((unsigned long long)w[0] | ((unsigned long long)w[1] << 32)) >> (q_begin & 31u)) & keep_all;
+                }
+            }
+        };
+        uint32_t k, hi, step;
+        if (dynamic) { step = 1u; claim(0u, k, hi); }
+        else { step = blocks_here * kWaves; k = (blockIdx.x / n_chunks) * kWaves + (uint32_t)wave; hi = n_items; }
+        uint32_t rec_k = kNone, rec_g = 0u, rec_keep = 0u;     // the record of an item read ahead
+        uint32_t ray_k = kNone;                                // W = 1: the item whose rays are in (or on their way to) nxt_a / nxt_b
+        auto advance = [&]() { k += step; if (dynamic && k >= hi) claim(hi, k, hi); };      // (dynamic: the batch is used up)
+        while (k < hi) {
+            RT_STAMP(ts_iter);
+            uint32_t g, keep;
+            if (rec_k == k) { g = rec_g; keep = rec_keep; } else item_of(k, g, keep);
+            const uint32_t wave_slot0 = g * 128u;
+            // the item after this one, if it is known already: its record (and with one wave per SIMD its rays) travel during the scan
+            const uint32_t succ = k + step < hi ? k + step : kNone;
+            if (succ != kNone) { item_of(succ, rec_g, rec_keep); rec_k = succ; }
+            if (kCount && cull && !dynamic && lane == 0)          // (dynamic launches count these in cull_items_kernel)
+                c_culled += (unsigned long long)__builtin_popcount(~keep & keep_all) * kMfQuadTris * min(128u, n_rays - wave_slot0);
+            if (keep == 0u) {                                  // (static, culled bounce) nothing of this chunk can be hit by this granule's rays
+                if constexpr (W == 1) { if (succ != kNone && rec_keep != 0u) { fetch_rays(rec_g, nxt_a, nxt_b); ray_k = succ; } }
+                advance();
+                continue;
+            }
+            MfRay ray[S];
             if constexpr (W == 1) {
+                if (ray_k != k) fetch_rays(g, nxt_a, nxt_b);
 #pragma unroll
-                for (int s = 0; s < S; ++s) { nxt_a[s] = nx2_a[s]; nxt_b[s] = nx2_b[s]; }
-                fetch_rays(base + 2u * kStride, nx2_a, nx2_b);
+                for (int s = 0; s < S; ++s) prepare_ray(ray[s], nxt_a[s], nxt_b[s], wave_slot0 + (uint32_t)s * 32u + (uint32_t)col < n_rays);
+                // the next item's rays travel while this one is scanned (one wave per SIMD: nothing else would hide the round trip)
+                if (succ != kNone && rec_keep != 0u) { fetch_rays(rec_g, nxt_a, nxt_b); ray_k = succ; }
             }
-            continue;
-        }
-        MfRay ray[S];
-        if constexpr (W == 1) {
-#pragma unroll
-            for (int s = 0; s < S; ++s) prepare_ray(ray[s], nxt_a[s], nxt_b[s], base + (uint32_t)(wave * S + s) * 32u + (uint32_t)col < n_rays);
-            // the next blocks' rays travel while this one is scanned (one wave per SIMD: nothing else would hide the round trip)
-#pragma unroll
-            for (int s = 0; s < S; ++s) { nxt_a[s] = nx2_a[s]; nxt_b[s] = nx2_b[s]; }
-            fetch_rays(base + 2u * kStride, nx2_a, nx2_b);
-        }
 
         uint32_t qn = 0;                                        // wave-uniform
         auto flush = [&]() {
@@ -418,7 +532,7 @@ scan_solo_kernel(SceneView sc, WaveBuffers wb, MfView mf, uint32_t bounce, uint3
         u32x4 B0, B1, B2, B3;                                   // B operands (K layout: see MfView) and thresholds of the four ray sets
         float th0, th1, th2, th3;
         f32x16 X0, X1, X2, X3, Y0, Y1, Y2, Y3;
-        f32x8 MA0, MA1, MA2, MA3, MB0, MB1, MB2, MB3;            // [0..4]: minima of the five triangles of the lane's half
+        f32x6 MA0, MA1, MA2, MA3, MB0, MB1, MB2, MB3;            // [0..4]: minima of the five triangles of the lane's half, [5]: their maximum
         unsigned long long any_a, any_b;                        // lanes with a survivor in the tile examined into MA / MB
         // rare path: some lane has a survivor in `tile` (index inside the chunk).  Branch-free: every lane builds the 20-bit mask of
         // its surviving (ray set, triangle) pairs from the minima the stage left behind, lanes with a non-empty mask append ONE entry
@@ -442,18 +556,18 @@ scan_solo_kernel(SceneView sc, WaveBuffers wb, MfView mf, uint32_t bounce, uint3
         for (uint32_t ts0 = 0; ts0 < n_tiles;) {
             RT_STAMP(ts_g0);
             const uint32_t q = q_begin + ts0 / kMfQuadTiles;
-            const uint32_t g = q >> group_shift;
-            const uint32_t ts1 = min(n_tiles, (((g + 1u) << group_shift) - q_begin) * kMfQuadTiles);
+            const uint32_t grp = q >> group_shift;
+            const uint32_t ts1 = min(n_tiles, (((grp + 1u) << group_shift) - q_begin) * kMfQuadTiles);
             // quads of this segment the wave still has to scan; a segment that is culled altogether costs nothing, not even its setup
             const uint32_t qa = ts0 / kMfQuadTiles, nq = (ts1 - ts0) / kMfQuadTiles;
             uint32_t seg = keep & ((nq >= 32u ? 0xFFFFFFFFu : ((1u << nq) - 1u)) << qa);
             if (seg == 0u) { ts0 = ts1; continue; }
             if constexpr (W == 2) {                              // nothing ray-related stays live across the tile loop: re-read the queue here
-                fetch_rays(base, nxt_a, nxt_b);
+                fetch_rays(g, nxt_a, nxt_b);
 #pragma unroll
-                for (int s = 0; s < S; ++s) prepare_ray(ray[s], nxt_a[s], nxt_b[s], base + (uint32_t)(wave * S + s) * 32u + (uint32_t)col < n_rays);
+                for (int s = 0; s < S; ++s) prepare_ray(ray[s], nxt_a[s], nxt_b[s], wave_slot0 + (uint32_t)s * 32u + (uint32_t)col < n_rays);
             }
-            const ConstFloats gp = groups_k + (size_t)g * (sizeof(MfGroup) / 4);
+            const ConstFloats gp = groups_k + (size_t)grp * (sizeof(MfGroup) / 4);
             MfGroup G;
             G.cx = gp[0]; G.cy = gp[1]; G.cz = gp[2]; G.E = gp[3]; G.Ml = gp[4]; G.Pw = gp[5]; G.P = gp[6]; G.pad1 = 0.0f;
             u32x4 Bs[S]; float ths[S];
@@ -529,19 +643,25 @@ scan_solo_kernel(SceneView sc, WaveBuffers wb, MfView mf, uint32_t bounce, uint3
         }
         RT_STAMP(ts_f0);
         flush();
+            advance();
         RT_STAMP(ts_f1);
         RT_STAMP_ADD(tt_flush, ts_f0, ts_f1);
 #ifdef RT_SOLO_STAMPS
-        tt_iters++;
+        tt_iters++; tt_tiles += n_tiles;
 #endif
+        }
+        if (!dynamic) break;                                   // static: a block stays with the chunk it started on
     }
 #ifdef RT_SOLO_STAMPS
     if (lane == 0 && mf.dbg_log) {
         unsigned long long *d = reinterpret_cast<unsigned long long *>(mf.dbg_log) + 16ull * bounce;
-        const unsigned long long ts_end = __builtin_amdgcn_s_memtime();
-        atomicAdd(d + 0, ts_end - ts_begin); atomicAdd(d + 1, tt_stage); atomicAdd(d + 2, tt_rays); atomicAdd(d + 3, tt_group);
+        const unsigned long long ts_end = RT_STAMP_NOW();
+        atomicAdd(d + 0, ts_end - ts_wave_begin); atomicAdd(d + 1, tt_stage); atomicAdd(d + 2, tt_rays); atomicAdd(d + 3, tt_group);
         atomicAdd(d + 4, tt_steady); atomicAdd(d + 5, tt_park); atomicAdd(d + 6, tt_flush); atomicAdd(d + 7, tt_iters); atomicAdd(d + 8, 1ull);
-        atomicAdd(d + 9, (unsigned long long)n_tiles * tt_iters);
+        atomicAdd(d + 9, tt_tiles);
+        if (blockIdx.x == 0 && wave == 0) d[15] = (unsigned long long)gridDim.x * kWaves;
+        atomicMax(d + 10, ts_end - ts_wave_begin);                // slowest wave of this launch: summed per bounce by the narrow phase
+        atomicAdd(d + 11, tt_culled); atomicAdd(d + 12, tt_culled_n);
     }
 #endif
     if (lane == 0) wb.cand_counts[region] = (uint32_t)(appended < (unsigned long long)wb.cand_region ? appended : (unsigned long long)wb.cand_region);
@@ -549,7 +669,7 @@ scan_solo_kernel(SceneView sc, WaveBuffers wb, MfView mf, uint32_t bounce, uint3
     if (kCount) {
         if (c_cand_lane) atomicAdd(&counters->candidates, c_cand_lane);
         if (c_culled) atomicAdd(&counters->culled_tests, c_culled);
-        if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&counters->tri_tests, (unsigned long long)n_rays * (v_chunk_end - v_chunk_begin));
+        if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&counters->tri_tests, (unsigned long long)n_rays * sc.n_tri_visits);
     }
 }
 
@@ -557,6 +677,12 @@ scan_solo_kernel(SceneView sc, WaveBuffers wb, MfView mf, uint32_t bounce, uint3
 // (:243-249) of every marked triangle, atomicMin merge.  One block per wave region of the scan launch that preceded it.
 __global__ void __launch_bounds__(256) narrow_phase_kernel(SceneView sc, WaveBuffers wb, MfView mf, uint32_t bounce, uint32_t n_regions)
 {
+#ifdef RT_SOLO_STAMPS
+    if (blockIdx.x == 0 && threadIdx.x == 0 && mf.dbg_log) {          // the slowest wave of the scan launch that just ended: summed per bounce
+        unsigned long long *d = reinterpret_cast<unsigned long long *>(mf.dbg_log) + 16ull * bounce;
+        d[13] += d[10]; d[10] = 0ull;
+    }
+#endif
     const RayQueue qin = (bounce & 1u) ? wb.q[1] : wb.q[0];
     unsigned long long *best = (bounce & 1u) ? wb.best[1] : wb.best[0];
     for (uint32_t r = blockIdx.x; r < n_regions; r += gridDim.x) {

@@ -48,7 +48,13 @@ struct WaveBuffers {
                                   // one region of `cand_region` pairs per wave of the scan launch
     uint32_t *cand_counts;        // kernel 4: pairs stored in each region by the scan launch of the current bounce
     uint32_t cand_region;         // capacity of one region (pairs); what does not fit is tested in place by the scan
-    float4 *packets;              // kernel 4 packet culling: three float4 per granule of 128 rays of the queue being scanned (rt_scan.hpp)
+    uint32_t *keep;               // kernel 4 packet culling: per granule of 128 rays of the queue being scanned, one bit per quad (rt_scan.hpp, packet_cull_kernel)
+    uint32_t keep_words;          // 32-bit words per granule = ceil(quads / 32)
+    uint2 *items;                 // kernel 4, culled bounces: per chunk of the scan launch the granules that have anything to scan, (granule, keep bits)
+    uint32_t *item_counts;        //   ... their number per chunk; items_stride entries are reserved per chunk (cull_items_kernel)
+    uint32_t items_stride;
+    uint32_t *sched;              // kernel 4: per scan launch (bounce) and chunk the next unclaimed item; zeroed with the ray counts at frame start
+    uint32_t sched_stride;        //   entries per bounce
     uint32_t *cand_peak;          // max over the frame's scan waves of the pairs a wave wanted to append (host: sizes the regions)
 };
 

@@ -189,7 +189,9 @@ struct rtgl_context {
     // kernel 4 candidate buffer: one region per wave of a scan launch.  Sized from what the scene needs, not from the image: it starts
     // at one record per ray and grows to 1.25 x the fullest region any finished frame reported (records that do not fit are tested
     // in place by the scan, so every size is correct; a too small one is only slower)
-    float4 *d_packets = nullptr; uint32_t packets_capacity = 0;
+    uint2 *d_items = nullptr; size_t items_capacity = 0;          // packet culling: per chunk of a culled scan launch its work items + one count per chunk
+    uint32_t *d_sched = nullptr; size_t sched_capacity = 0;       // kernel 4: next unclaimed item per (bounce, chunk)
+    uint32_t *d_keep = nullptr; size_t keep_capacity = 0;         // packet culling: (granules of 128 rays) x (quads / 32) words
     uint2 *d_cand = nullptr; uint32_t cand_regions = 0, cand_region_pairs = 0, cand_region_target = 0; bool cand_fixed = false;
     bool solo_attr_set = false;              // hipFuncAttributeMaxDynamicSharedMemorySize is per device: raised once per context (= per device binding)
     bool group_explicit = false;             // "mf_group_quads" was set through rtgl_set_option
@@ -207,7 +209,7 @@ struct rtgl_context {
     bool tris_dirty = false, visits_dirty = false;
     FrameParams params{};
     bool have_params = false;
-    int opt_kernel = RTGL_KERNEL_WAVEFRONT_MFMA_SOLO, opt_rng_state = 0, opt_counters = 0, opt_kernel_timing = 0, opt_wf_rays = 4, opt_wf_mode = kLds, opt_wf_chunk = 256, opt_wf_early = 0, opt_wf_packed = 0, opt_mf_chunk_quads = 32, opt_mf_group_quads = 32, opt_cull = 1, opt_scan_waves = 0, opt_debug_skip_exact = 0;
+    int opt_kernel = RTGL_KERNEL_WAVEFRONT_MFMA_SOLO, opt_rng_state = 0, opt_counters = 0, opt_kernel_timing = 0, opt_wf_rays = 4, opt_wf_mode = kLds, opt_wf_chunk = 256, opt_wf_early = 0, opt_wf_packed = 0, opt_mf_chunk_quads = 32, opt_mf_group_quads = 32, opt_cull = 1, opt_scan_waves = 0, opt_scan_dynamic = 0, opt_debug_skip_exact = 0;
 };
 
 static int fail(rtgl_context *ctx, int code, const std::string &msg)
@@ -270,6 +272,7 @@ extern "C" int rtgl_create_tiled(rtgl_context **out, int width, int height, int 
     // operational override of the default scan without touching the caller: RTGL_AMD_KERNEL=0, 1, 2 or 4 (rtgl_set_option still wins)
     if (const char *k = getenv("RTGL_AMD_KERNEL")) { const int v = atoi(k); if (v >= RTGL_KERNEL_MEGA && v <= RTGL_KERNEL_WAVEFRONT_MFMA_SOLO && v != RTGL_KERNEL_REMOVED_3) { ctx->opt_kernel = v; ctx->kernel_explicit = true; } }
     if (const char *k = getenv("RTGL_AMD_SCAN_WAVES")) { const int v = atoi(k); if (v >= 0 && v <= 2) ctx->opt_scan_waves = v; }   // A/B of the scan's occupancy
+    if (const char *k = getenv("RTGL_AMD_SCAN_DYNAMIC")) { const int v = atoi(k); if (v >= 0 && v <= 2) ctx->opt_scan_dynamic = v; }   // ... and of its work distribution
     *out = ctx;
     return RTGL_OK;
 }
@@ -293,15 +296,15 @@ extern "C" void rtgl_destroy(rtgl_context *ctx)
         if (hipMemcpy(h, ctx->d_dbg_log, sizeof h, hipMemcpyDeviceToHost) == hipSuccess)
             for (int b = 0; b < 64 && h[16 * b + 8]; ++b) {
                 const unsigned long long *d = h + 16 * b; const double tot = (double)d[0];
-                fprintf(stderr, "rtgl stamps bounce %2d: waves %llu iters %llu  cycles/wave %.0f  staging %.1f%% rays %.1f%% group+prologue %.1f%% steady %.1f%% (park %.1f%%) flush %.1f%%  cycles per tile-stage in steady %.1f\n",
+                fprintf(stderr, "rtgl stamps bounce %2d: waves %llu iters %llu  cycles/wave %.0f  staging %.1f%% rays %.1f%% group+prologue %.1f%% steady %.1f%% (park %.1f%%) flush %.1f%%  cycles per tile-stage in steady %.1f  slowest wave of a launch (mean over launches) %.0f  culled items %llu at %.0f cycles\n",
                         b, d[8], d[7], tot / d[8], 100.0 * d[1] / tot, 100.0 * d[2] / tot, 100.0 * d[3] / tot, 100.0 * d[4] / tot, 100.0 * d[5] / tot, 100.0 * d[6] / tot,
-                        d[9] ? (double)d[4] / (double)d[9] : 0.0);
+                        d[9] ? (double)d[4] / (double)d[9] : 0.0, (double)d[13] * (double)d[15] / (double)d[8], d[12], d[12] ? (double)d[11] / (double)d[12] : 0.0);
             }
     }
 #endif
     void *ptrs[] = { ctx->d_spheres, ctx->d_materials, ctx->d_vertices, ctx->d_sphere_visits, ctx->d_edges, ctx->d_planes,
                      ctx->d_env, ctx->d_image_own, ctx->d_rng, ctx->d_counters, ctx->d_u8, ctx->d_group_bounds, ctx->d_wave, ctx->d_counts, ctx->d_mf_groups, ctx->d_mf_A, ctx->d_mf_order,
-                     ctx->d_dbg_log, ctx->d_cand, ctx->d_mf_cull, ctx->d_packets };
+                     ctx->d_dbg_log, ctx->d_cand, ctx->d_mf_cull, ctx->d_keep, ctx->d_items, ctx->d_sched };
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (hipEvent_t e : ctx->kev) (void)hipEventDestroy(e);
     if (ctx->h_counts) (void)hipHostFree(ctx->h_counts);
@@ -336,6 +339,11 @@ extern "C" int rtgl_create_multi(rtgl_context **out, int width, int height, cons
         rtgl_context *part = nullptr;
         rc = rtgl_create_tiled(&part, width, height, devices[i], i, n_devices, strip_rows);
         if (rc) { const std::string msg = g_create_error; rtgl_destroy(ctx); g_create_error = msg; return rc; }
+        // Parts that share a device share a stream: their kernels never run beside each other.  (Independent contexts rendering
+        // CONCURRENTLY on one device are not safe with kernel 4 on the pool's MI355X boxes: every few hundred frames 16 rays of one
+        // launch lose their mesh hit -- DESIGN.md 5.2, tools/diagnostics/flaky_tiled.py.  Several GPUs, one context each, is the
+        // configuration this entry point exists for.)
+        for (int j = 0; j < i; ++j) if (devices[j] == devices[i]) { part->stream = ctx->parts[j]->stream; break; }
         ctx->parts.push_back(part);
         hipEvent_t ev = nullptr;
         (void)hipSetDevice(devices[i]);
@@ -571,9 +579,10 @@ static int rebuild_triangles(rtgl_context *ctx)
         if (ctx->d_mf_A) { HIPCHK(ctx, hipFree(ctx->d_mf_A)); ctx->d_mf_A = nullptr; }
         if (ctx->d_mf_order) { HIPCHK(ctx, hipFree(ctx->d_mf_order)); ctx->d_mf_order = nullptr; }
         if (ctx->d_mf_cull) { HIPCHK(ctx, hipFree(ctx->d_mf_cull)); ctx->d_mf_cull = nullptr; }
-        // quads sharing one local origin: 32 unless the caller chose; a dense mesh (>= 50k triangles) gets 8 -- its triangles are small
-        // against the group, so the survivors (and the time spent parking them) follow the group size more than at 10k (C4: +7 %)
-        ctx->mf_group_quads = ctx->group_explicit ? (uint32_t)ctx->opt_mf_group_quads : (visit_tri.size() >= 50000 ? 8u : 32u);
+        // quads sharing one local origin: 32 (= a chunk: one ray set-up per work item of the scan) unless the caller chose.  Smaller
+        // groups have tighter bounds and fewer survivors (C4: 89 M per frame at 8 quads against 111 M at 32), but every group of a
+        // chunk costs the scan a ray set-up and a pipeline fill of its own: 28.4 against 30.0 Mpaths/s
+        ctx->mf_group_quads = ctx->group_explicit ? (uint32_t)ctx->opt_mf_group_quads : 32u;
         const uint32_t group_tris = ctx->mf_group_quads * kMfQuadTris;
         ctx->n_mf_groups = (ctx->n_tri_visits + group_tris - 1) / group_tris;
         const std::vector<uint32_t> order = morton_order(ctx, visit_tri);
@@ -636,12 +645,28 @@ static int ensure_wave_buffers(rtgl_context *ctx, uint32_t n0, uint32_t max_boun
             ctx->cand_regions = need_regions; ctx->cand_region_pairs = ctx->cand_region_target;
             HIPCHK(ctx, hipMalloc((void **)&ctx->d_cand, ((size_t)need_regions * ctx->cand_region_pairs) * sizeof(uint2) + (size_t)need_regions * sizeof(uint32_t) + 256));
         }
-        if (ctx->packets_capacity < n0) {                      // packet-culling records: 48 B per 128 rays
-            if (ctx->d_packets) { HIPCHK(ctx, hipFree(ctx->d_packets)); ctx->d_packets = nullptr; }
-            HIPCHK(ctx, hipMalloc((void **)&ctx->d_packets, ((size_t)n0 / 128 + 2) * 3 * sizeof(float4)));
-            ctx->packets_capacity = n0;
+        {                                                    // packet culling: one bit per (granule of 128 rays, quad); + 16 granules read ahead of the last one
+            const uint32_t real_quads = std::min(ctx->n_mf_groups * ctx->mf_group_quads, (ctx->n_tri_visits + (uint32_t)kMfQuadTris - 1) / (uint32_t)kMfQuadTris);
+            ctx->wb.keep_words = std::max(1u, (real_quads + 31u) / 32u);
+            const size_t need = ((size_t)n0 / 128 + 16) * ctx->wb.keep_words;
+            if (ctx->keep_capacity < need) {
+                if (ctx->d_keep) { HIPCHK(ctx, hipFree(ctx->d_keep)); ctx->d_keep = nullptr; }
+                HIPCHK(ctx, hipMalloc((void **)&ctx->d_keep, need * sizeof(uint32_t)));
+                ctx->keep_capacity = need;
+            }
         }
-        ctx->wb.packets = ctx->d_packets;
+        ctx->wb.keep = ctx->d_keep;
+        {                                                    // work distribution of the scan: one counter per (bounce, chunk); a launch has at most max(CUs, chunks) chunks
+            ctx->wb.sched_stride = std::max<uint32_t>((uint32_t)ctx->n_cus, solo_chunks(ctx));
+            const size_t need = (size_t)(max_bounce + 2) * ctx->wb.sched_stride;
+            if (ctx->sched_capacity < need) {
+                if (ctx->d_sched) { HIPCHK(ctx, hipFree(ctx->d_sched)); ctx->d_sched = nullptr; }
+                HIPCHK(ctx, hipMalloc((void **)&ctx->d_sched, need * sizeof(uint32_t)));
+                ctx->sched_capacity = need;
+            }
+            ctx->wb.sched = ctx->d_sched;
+        }
+        ctx->wb.items = ctx->d_items; ctx->wb.item_counts = reinterpret_cast<uint32_t *>(ctx->d_items);     // (allocated by the first culled launch)
         ctx->wb.cand = ctx->d_cand;
         ctx->wb.cand_counts = reinterpret_cast<uint32_t *>(ctx->d_cand + (size_t)ctx->cand_regions * ctx->cand_region_pairs);
         ctx->wb.cand_region = ctx->cand_region_pairs;
@@ -719,6 +744,14 @@ static uint32_t solo_chunks(const rtgl_context *ctx)
     return (real_quads + chunk_quads - 1) / chunk_quads;
 }
 
+// work distribution of the scan (rt_scan.hpp): "scan_dynamic" 0 = by the mesh (dynamic from 1,024 quads = 41k triangles on: few blocks
+// per chunk), 1 = static, 2 = dynamic
+static int solo_dynamic(const rtgl_context *ctx)
+{
+    const uint32_t real_quads = std::min(ctx->n_mf_groups * ctx->mf_group_quads, (ctx->n_tri_visits + (uint32_t)kMfQuadTris - 1) / (uint32_t)kMfQuadTris);
+    return ctx->opt_scan_dynamic ? ctx->opt_scan_dynamic - 1 : (real_quads >= 1024u ? 1 : 0);
+}
+
 static int launch_intersect_solo(rtgl_context *ctx, const SceneView &sc, uint32_t n0, uint32_t bounce)
 {
     const uint32_t gq = ctx->mf_group_quads, n_quads = ctx->n_mf_groups * gq;
@@ -731,20 +764,23 @@ static int launch_intersect_solo(rtgl_context *ctx, const SceneView &sc, uint32_
     const uint32_t base_chunks = (real_quads + std::min((uint32_t)ctx->opt_mf_chunk_quads, std::max(real_quads, 1u)) - 1) / std::min((uint32_t)ctx->opt_mf_chunk_quads, std::max(real_quads, 1u));
     const uint32_t W = ctx->opt_scan_waves ? (uint32_t)ctx->opt_scan_waves
                                            : (((uint64_t)((est + 8u * Cfg::kRaysPerWave - 1u) / (8u * Cfg::kRaysPerWave)) * base_chunks >= 4ull * (uint32_t)ctx->n_cus) ? 2u : 1u);
-    const uint32_t waves = 4u * W, rays_per_block = waves * Cfg::kRaysPerWave;
-    const uint32_t blocks_x_all = (est + rays_per_block - 1u) / rays_per_block;
-    // A launch has (ray blocks x chunks) work items for one block per CU.  Late bounces (and every bounce of a rank that owns an
-    // eighth of the image) have few ray blocks: cut the triangle range finer, down to 4 quads per chunk, until there are two items
-    // per CU (each item pays its ray and group set-up again, ~20 % at 8 quads, so only as far as needed; never more chunks than CUs:
-    // the candidate regions are one per wave of a full-width launch)
+    const uint32_t waves = 4u * W;
+    const uint32_t est_gran = (est + Cfg::kRaysPerWave - 1u) / Cfg::kRaysPerWave;
+    // A launch has (granules x chunks) work items for its waves, claimed dynamically (rt_scan.hpp).  Late bounces (and every bounce of a
+    // rank that owns an eighth of the image) have few granules: cut the triangle range finer, down to 4 quads per chunk, until there are
+    // two items per wave (each item pays its ray and group set-up again, ~20 % at 8 quads, so only as far as needed; never more chunks
+    // than CUs)
     uint32_t chunk_quads = std::min((uint32_t)ctx->opt_mf_chunk_quads, std::max(real_quads, 1u));
-    while (chunk_quads > 4u && (uint64_t)blocks_x_all * ((real_quads + chunk_quads - 1) / chunk_quads) < 2ull * (uint32_t)ctx->n_cus
+    while (chunk_quads > 4u && (uint64_t)est_gran * ((real_quads + chunk_quads - 1) / chunk_quads) < 2ull * (uint32_t)ctx->n_cus * waves
            && (real_quads + chunk_quads / 2 - 1) / (chunk_quads / 2) <= (uint32_t)ctx->n_cus)
         chunk_quads /= 2u;
     const uint32_t chunks = (real_quads + chunk_quads - 1) / chunk_quads;
-    // one block per CU in total: with more, the surplus runs as a second, mostly empty round
-    const uint32_t blocks_x = std::max(1u, std::min(blocks_x_all, (uint32_t)ctx->n_cus / chunks));
-    const size_t lds = std::max<size_t>(((size_t)chunk_quads * kMfQuadTiles + 4) * 1024 + (size_t)chunk_quads * sizeof(MfCull), 96 * 1024);   // + the four rows read two trips ahead behind the last tile; > half of the CU's LDS with the static queue: one block per CU
+    const int dynamic = solo_dynamic(ctx);
+    // one block per CU (forced by the LDS request); fewer when there is not an item per wave.  Static: the same number of blocks on
+    // every chunk.
+    uint32_t blocks = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(((uint64_t)est_gran * chunks + waves - 1) / waves, (uint64_t)ctx->n_cus));
+    if (!dynamic) blocks = std::max(1u, std::min((est_gran + waves - 1u) / waves, std::max(1u, (uint32_t)ctx->n_cus / chunks))) * chunks;
+    const size_t lds = std::max<size_t>(((size_t)chunk_quads * kMfQuadTiles + 4) * 1024, 96 * 1024);   // + the four rows read two trips ahead behind the last tile; > half of the CU's LDS with the static queue: one block per CU
 #ifdef RT_SOLO_STAMPS
     if (!ctx->d_dbg_log) { HIPCHK(ctx, hipMalloc((void **)&ctx->d_dbg_log, (size_t)(2 + (2u << 22)) * 4)); HIPCHK(ctx, hipMemsetAsync(ctx->d_dbg_log, 0, 16 * 8 * 64, ctx->stream)); }
 #endif
@@ -760,19 +796,34 @@ static int launch_intersect_solo(rtgl_context *ctx, const SceneView &sc, uint32_
         }
         ctx->solo_attr_set = true;
     }
-    dim3 grid(blocks_x, chunks);
     // packet culling pays where the 128 rays of a wave are coherent: the camera rays (option "cull": 0 never, 1 bounce 0 (default), 2 every bounce)
     const int cull = ctx->opt_cull == 2 || (ctx->opt_cull == 1 && bounce == 0);
     if (cull) {
-        const uint32_t gran = (est + 127u) / 128u;
-        hipLaunchKernelGGL(packet_bounds_kernel, dim3(std::max(1u, std::min((gran + 3u) / 4u, 4096u))), dim3(256), 0, ctx->stream, ctx->wb, bounce);
+        hipLaunchKernelGGL(packet_cull_kernel, dim3(std::max(1u, std::min((est_gran + 3u) / 4u, 8192u))), dim3(256), 0, ctx->stream, ctx->wb, ctx->d_mf_cull, real_quads, bounce);
+        if (dynamic) {
+        // work items of the culled launch: [one count per chunk][chunks x (granules of the whole image) entries]
+        const uint32_t stride = n0 / Cfg::kRaysPerWave + 1u;
+        const size_t head = ((size_t)ctx->wb.sched_stride * sizeof(uint32_t) + 255) & ~(size_t)255, need = head + (size_t)chunks * stride * sizeof(uint2);
+        if (ctx->items_capacity < need) {
+            if (ctx->d_items) { HIPCHK(ctx, hipFree(ctx->d_items)); ctx->d_items = nullptr; }
+            HIPCHK(ctx, hipMalloc((void **)&ctx->d_items, need));
+            ctx->items_capacity = need;
+        }
+        ctx->wb.item_counts = reinterpret_cast<uint32_t *>(ctx->d_items);
+        ctx->wb.items = reinterpret_cast<uint2 *>(reinterpret_cast<uint8_t *>(ctx->d_items) + head);
+        ctx->wb.items_stride = stride;
+        HIPCHK(ctx, hipMemsetAsync(ctx->wb.item_counts, 0, (size_t)chunks * sizeof(uint32_t), ctx->stream));
+        const dim3 igrid(std::max(1u, std::min((est_gran + 255u) / 256u, 1024u)), chunks);
+        if (ctx->opt_counters) hipLaunchKernelGGL(cull_items_kernel<true>, igrid, dim3(256), 0, ctx->stream, ctx->wb, bounce, chunk_quads, real_quads, ctx->d_counters);
+        else hipLaunchKernelGGL(cull_items_kernel<false>, igrid, dim3(256), 0, ctx->stream, ctx->wb, bounce, chunk_quads, real_quads, ctx->d_counters);
+        }
     }
-#define RTGL_LAUNCH_SCAN(C, WW) hipLaunchKernelGGL((scan_solo_kernel<C, WW>), grid, dim3(256 * WW), lds, ctx->stream, sc, ctx->wb, mf, bounce, chunk_quads, ctx->d_counters, ctx->opt_debug_skip_exact, cull)
+#define RTGL_LAUNCH_SCAN(C, WW) hipLaunchKernelGGL((scan_solo_kernel<C, WW>), dim3(blocks), dim3(256 * WW), lds, ctx->stream, sc, ctx->wb, mf, bounce, chunk_quads, chunks, ctx->d_counters, ctx->opt_debug_skip_exact, cull, dynamic)
     if (W == 2) { if (ctx->opt_counters) RTGL_LAUNCH_SCAN(true, 2); else RTGL_LAUNCH_SCAN(false, 2); }
     else { if (ctx->opt_counters) RTGL_LAUNCH_SCAN(true, 1); else RTGL_LAUNCH_SCAN(false, 1); }
 #undef RTGL_LAUNCH_SCAN
     HIPCHK(ctx, hipGetLastError());
-    hipLaunchKernelGGL(narrow_phase_kernel, dim3(blocks_x * chunks * waves), dim3(256), 0, ctx->stream, sc, ctx->wb, mf, bounce, blocks_x * chunks * waves);
+    hipLaunchKernelGGL(narrow_phase_kernel, dim3(blocks * waves), dim3(256), 0, ctx->stream, sc, ctx->wb, mf, bounce, blocks * waves);
     return RTGL_OK;
 }
 
@@ -790,6 +841,8 @@ static int launch_wavefront(rtgl_context *ctx, const SceneView &sc, const FrameP
     }
     for (uint32_t s = 0; s < P.samples; ++s) {
         HIPCHK(ctx, hipMemsetAsync(ctx->d_counts, 0, counts_bytes(ctx->counts_capacity), ctx->stream));
+        if (ctx->opt_kernel == RTGL_KERNEL_WAVEFRONT_MFMA_SOLO && ctx->d_sched && solo_dynamic(ctx))       // the scan launches' work counters (rt_scan.hpp)
+            HIPCHK(ctx, hipMemsetAsync(ctx->d_sched, 0, (size_t)(P.max_bounce + 2) * ctx->wb.sched_stride * sizeof(uint32_t), ctx->stream));
         hipLaunchKernelGGL(generate_rays_kernel, gen_grid, dim3(256), 0, ctx->stream, P, im, ctx->wb, s, n0,
                            ctx->opt_counters ? ctx->d_counters : (Counters *)nullptr);
         for (uint32_t b = 0; b < P.max_bounce; ++b) {
@@ -1147,6 +1200,9 @@ extern "C" int rtgl_set_option(rtgl_context *ctx, const char *key, int value)
     } else if (!strcmp(key, "scan_waves")) {
         if (value < 0 || value > 2) return fail(ctx, RTGL_ERR_INVALID, "scan_waves (waves per SIMD of the kernel-4 scan) must be 0 (chosen per launch), 1 or 2");
         ctx->opt_scan_waves = value;
+    } else if (!strcmp(key, "scan_dynamic")) {
+        if (value < 0 || value > 2) return fail(ctx, RTGL_ERR_INVALID, "scan_dynamic must be 0 (chosen by the mesh), 1 (static) or 2 (dynamic)");
+        ctx->opt_scan_dynamic = value;
     } else if (!strcmp(key, "cull")) {
         if (value < 0 || value > 2) return fail(ctx, RTGL_ERR_INVALID, "cull must be 0 (off), 1 (camera rays) or 2 (every bounce)");
         ctx->opt_cull = value;
@@ -1189,6 +1245,7 @@ extern "C" int rtgl_get_option(rtgl_context *ctx, const char *key, int *value)
     else if (!strcmp(key, "mf_group_quads")) *value = (int)ctx->mf_group_quads;
     else if (!strcmp(key, "cull")) *value = ctx->opt_cull;
     else if (!strcmp(key, "scan_waves")) *value = ctx->opt_scan_waves;
+    else if (!strcmp(key, "scan_dynamic")) *value = ctx->opt_scan_dynamic;
     else if (!strcmp(key, "rng_state")) *value = ctx->opt_rng_state;
     else if (!strcmp(key, "counters")) *value = ctx->opt_counters;
     else if (!strcmp(key, "kernel_timing")) *value = ctx->opt_kernel_timing;

@@ -66,7 +66,7 @@ def cull_record(tri):
 
 
 def packet_bounds(o, d):
-    """packet_bounds_kernel: origin sphere, direction cone, |o| bound."""
+    """packet_cull_kernel: origin sphere, direction cone, |o| bound."""
     o, d = o.astype(f32), d.astype(f32)
     dh = d / np.sqrt(dot3(d, d))[:, None]
     O = f32(0.5) * o.min(0) + f32(0.5) * o.max(0)
@@ -79,7 +79,7 @@ def packet_bounds(o, d):
 
 
 def certified(rec, pk):
-    """the per-quad test of scan_solo_kernel"""
+    """the per-quad test of packet_cull_kernel"""
     if not pk["usable"]:
         return False
     w = rec["c"] - pk["O"]

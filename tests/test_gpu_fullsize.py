@@ -213,6 +213,37 @@ def test_multi_device_context_through_the_c_abi_matches_single_context(devices, 
     assert cnt["paths"] == cnt_ref["paths"] and cnt["segments"] == cnt_ref["segments"]
 
 
+@pytest.mark.parametrize("opts", [(), (("scan_waves", 1), ("cull", 0)), (("scan_waves", 2),), (("mf_chunk_quads", 4),)])
+def test_three_contexts_sharing_one_device_repeat_the_reference_image(opts, rt):
+    """Regression for the co-residency fault found in round 2: while the one-wave-per-SIMD scan left room on its SIMDs,
+    kernels of the OTHER contexts rendering on the same device ran beside it and every few runs a frame came out with 16 wrong pixels
+    (10-40 % of the runs of exactly this scenario, tools/diagnostics/flaky_multi.py).  The scan now claims the whole register file of
+    its SIMDs; 25 repetitions per option set must all equal the fp32-scan reference bit for bit."""
+    sc = rt.scenes
+    W, H = 328, 204
+    scene = sc.scene_mesh(30, 10, env_size=32)
+    base = sc.params_c2()
+    g = sc.GlibcRand(0)
+    plist = [base.replace(frames=f, random=g.rand()) for f in range(1, 4)]
+
+    def run(options, **kw):
+        ctx = rt.host.Context(W, H, **kw)
+        for k, v in options:
+            ctx.set_option(k, v)
+        ctx.upload_scene(scene)
+        for p in plist:
+            ctx.render(p)
+        img = ctx.read_image()
+        ctx.close()
+        return img
+
+    ref = run((("kernel", 2),))
+    for it in range(25):
+        img = run(opts, devices=[0, 0, 0], strip_rows=8)
+        d = (img.view(np.uint32) != ref.view(np.uint32)).any(axis=2)
+        assert not d.any(), f"repetition {it}: {int(d.sum())} pixels differ at {list(zip(*np.nonzero(d)))[:16]}"
+
+
 @pytest.mark.parametrize("cfg_name,cull", [("C2", 1), ("C2", 2), ("C5", 1)])
 def test_packet_culling_skips_most_camera_ray_tests_and_changes_nothing(cfg_name, cull, rt):
     """Packet culling (rt_mfma.hpp MfCull): a wave skips the quads for which every one of its 128 rays is certified to be rejected
