@@ -322,11 +322,12 @@ __global__ void __launch_bounds__(256) cull_items_kernel(WaveBuffers wb, uint32_
 //     a launch has few blocks per chunk and the chunks differ (C4: 79 chunks for 256 CUs, camera rays culled for some chunks and not
 //     for others: the static launch lasted 1.33x its mean wave; dynamic: 29.9 -> 33.9 Mpaths/s.  On C2 the static form is 14 %
 //     faster: 8 chunks, 32 blocks each).
-template <bool kCount, int W>
+template <bool kCount, int W, bool kDyn>
 __global__ void __launch_bounds__(256 * W) __attribute__((amdgpu_waves_per_eu(W, W)))
-scan_solo_kernel(SceneView sc, WaveBuffers wb, MfView mf, uint32_t bounce, uint32_t chunk_quads, uint32_t n_chunks, Counters *__restrict__ counters, int debug_skip_exact, int cull, int dynamic)
+scan_solo_kernel(SceneView sc, WaveBuffers wb, MfView mf, uint32_t bounce, uint32_t chunk_quads, uint32_t n_chunks, Counters *__restrict__ counters, int debug_skip_exact, int cull)
 {
     using Cfg = SoloCfg;
+    constexpr bool dynamic = kDyn;                             // (a template parameter: the static form carries none of the claiming state)
     constexpr int S = kSoloSets;
     constexpr uint32_t kWaves = 4u * (uint32_t)W, kThreads = 256u * (uint32_t)W;
     extern __shared__ uint4 lds_tiles[];                      // the chunk's A tiles, [quad][tile][panel][row]

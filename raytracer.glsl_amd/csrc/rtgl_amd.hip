@@ -788,8 +788,10 @@ static int launch_intersect_solo(rtgl_context *ctx, const SceneView &sc, uint32_
     if (!ctx->solo_attr_set) {
         // allow the whole LDS of a CU (160 KB) minus the kernel's static share as dynamic shared memory.  The attribute belongs to the
         // (function, device) pair, so it is raised once per context -- a context is bound to one device -- not once per process.
-        for (const void *fn : {reinterpret_cast<const void *>(&scan_solo_kernel<false, 1>), reinterpret_cast<const void *>(&scan_solo_kernel<true, 1>),
-                               reinterpret_cast<const void *>(&scan_solo_kernel<false, 2>), reinterpret_cast<const void *>(&scan_solo_kernel<true, 2>)}) {
+        for (const void *fn : {reinterpret_cast<const void *>(&scan_solo_kernel<false, 1, false>), reinterpret_cast<const void *>(&scan_solo_kernel<true, 1, false>),
+                               reinterpret_cast<const void *>(&scan_solo_kernel<false, 2, false>), reinterpret_cast<const void *>(&scan_solo_kernel<true, 2, false>),
+                               reinterpret_cast<const void *>(&scan_solo_kernel<false, 1, true>), reinterpret_cast<const void *>(&scan_solo_kernel<true, 1, true>),
+                               reinterpret_cast<const void *>(&scan_solo_kernel<false, 2, true>), reinterpret_cast<const void *>(&scan_solo_kernel<true, 2, true>)}) {
             hipFuncAttributes fattr;
             HIPCHK(ctx, hipFuncGetAttributes(&fattr, fn));
             HIPCHK(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024 - fattr.sharedSizeBytes)));
@@ -818,9 +820,11 @@ static int launch_intersect_solo(rtgl_context *ctx, const SceneView &sc, uint32_
         else hipLaunchKernelGGL(cull_items_kernel<false>, igrid, dim3(256), 0, ctx->stream, ctx->wb, bounce, chunk_quads, real_quads, ctx->d_counters);
         }
     }
-#define RTGL_LAUNCH_SCAN(C, WW) hipLaunchKernelGGL((scan_solo_kernel<C, WW>), dim3(blocks), dim3(256 * WW), lds, ctx->stream, sc, ctx->wb, mf, bounce, chunk_quads, chunks, ctx->d_counters, ctx->opt_debug_skip_exact, cull, dynamic)
-    if (W == 2) { if (ctx->opt_counters) RTGL_LAUNCH_SCAN(true, 2); else RTGL_LAUNCH_SCAN(false, 2); }
-    else { if (ctx->opt_counters) RTGL_LAUNCH_SCAN(true, 1); else RTGL_LAUNCH_SCAN(false, 1); }
+#define RTGL_LAUNCH_SCAN(C, WW, D) hipLaunchKernelGGL((scan_solo_kernel<C, WW, D>), dim3(blocks), dim3(256 * WW), lds, ctx->stream, sc, ctx->wb, mf, bounce, chunk_quads, chunks, ctx->d_counters, ctx->opt_debug_skip_exact, cull)
+#define RTGL_LAUNCH_SCAN_W(C, D) do { if (W == 2) RTGL_LAUNCH_SCAN(C, 2, D); else RTGL_LAUNCH_SCAN(C, 1, D); } while (0)
+    if (dynamic) { if (ctx->opt_counters) RTGL_LAUNCH_SCAN_W(true, true); else RTGL_LAUNCH_SCAN_W(false, true); }
+    else { if (ctx->opt_counters) RTGL_LAUNCH_SCAN_W(true, false); else RTGL_LAUNCH_SCAN_W(false, false); }
+#undef RTGL_LAUNCH_SCAN_W
 #undef RTGL_LAUNCH_SCAN
     HIPCHK(ctx, hipGetLastError());
     hipLaunchKernelGGL(narrow_phase_kernel, dim3(blocks * waves), dim3(256), 0, ctx->stream, sc, ctx->wb, mf, bounce, blocks * waves);
