@@ -215,10 +215,11 @@ def test_multi_device_context_through_the_c_abi_matches_single_context(devices, 
 
 @pytest.mark.parametrize("opts", [(), (("scan_waves", 1), ("cull", 0)), (("scan_waves", 2),), (("mf_chunk_quads", 4),)])
 def test_three_contexts_sharing_one_device_repeat_the_reference_image(opts, rt):
-    """Regression for the co-residency fault found in round 2: while the one-wave-per-SIMD scan left room on its SIMDs,
-    kernels of the OTHER contexts rendering on the same device ran beside it and every few runs a frame came out with 16 wrong pixels
-    (10-40 % of the runs of exactly this scenario, tools/diagnostics/flaky_multi.py).  The scan now claims the whole register file of
-    its SIMDs; 25 repetitions per option set must all equal the fp32-scan reference bit for bit."""
+    """Round 2 found that several kernel-4 pipelines rendering CONCURRENTLY on one device come back, every few dozen to few hundred
+    runs, with 16 rays of one launch having lost their mesh hit (tools/diagnostics/flaky_tiled.py reproduces it with
+    independent contexts; the cause is not established).  Parts of rtgl_create_multi that share a device therefore share a stream:
+    their kernels never run beside each other.  25 repetitions per option set of exactly the scenario that used to fail in 10-40 % of
+    the runs must all equal the fp32-scan reference bit for bit."""
     sc = rt.scenes
     W, H = 328, 204
     scene = sc.scene_mesh(30, 10, env_size=32)
