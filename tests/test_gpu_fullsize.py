@@ -100,6 +100,22 @@ def test_c4_100k_triangles_variants_agree_and_match_oracle_strip(rt, oracle):
     assert (a[536:544].view(np.uint32) == want[536:544].view(np.uint32)).all()
 
 
+@pytest.mark.parametrize("cfg_name,opts", [("C2", (("scan_dynamic", 2),)), ("C2", (("scan_dynamic", 2), ("scan_waves", 1), ("cull", 2))), ("C2", (("scan_dynamic", 1), ("scan_waves", 2), ("cull", 2))),
+                                           ("C4", (("scan_dynamic", 1),)), ("C4", (("scan_dynamic", 2), ("scan_waves", 1), ("mf_group_quads", 8)))])
+def test_static_and_dynamic_work_distribution_agree(cfg_name, opts, rt):
+    """The scan's two ways of handing (granule, chunk) items to its waves (static turns / claimed from counters; rt_scan.hpp) at full
+    size, forced against the default (C2: static, C4: dynamic), with one and two waves per SIMD and the cull on every bounce: the same
+    image bit for bit, the same survivor and test counts."""
+    a, ca = render(rt, cfg_name, frames=2, counters=True)[:2]
+    b, cb = render(rt, cfg_name, frames=2, options=opts, counters=True)[:2]
+    assert (a.view(np.uint32) == b.view(np.uint32)).all()
+    assert ca["segments"] == cb["segments"] and ca["triangle_tests"] == cb["triangle_tests"]
+    if not any(k == "mf_group_quads" for k, _ in opts):
+        assert ca["candidates"] == cb["candidates"]
+    if not any(k == "cull" for k, _ in opts):
+        assert ca["culled_tests"] == cb["culled_tests"]
+
+
 def test_c5_2160p_16_bounces_wide_dof(rt, oracle):
     a, cnt, _, scene, plist = render(rt, "C5", frames=1, counters=True)
     assert cnt["paths"] == 3840 * 2160 and cnt["segments"] <= cnt["paths"] * 16

@@ -52,6 +52,17 @@ def test_one_wave_per_simd_scan_matches_reference_shader_output(path, rt):
     assert (img.view(np.uint32) == expected.view(np.uint32)).all()
 
 
+@pytest.mark.parametrize("waves", [1, 2])
+@pytest.mark.parametrize("path", CASE_FILES, ids=lambda p: os.path.basename(p)[:-4])
+def test_dynamic_work_distribution_matches_reference_shader_output(path, waves, rt):
+    """kernel 4 with its items claimed from counters (rt_scan.hpp, `scan_dynamic` = 2: the default only from 41k triangles on), chunks of
+    two quads so that the small golden meshes have several chunks for the blocks to move between, the cull on every bounce (its
+    compacted item lists), one and two waves per SIMD -- every golden case."""
+    meta, scene, frames, expected = load_case(path, rt)
+    img = render_case(rt, meta, scene, frames, options=(("kernel", 4), ("scan_dynamic", 2), ("scan_waves", waves), ("mf_chunk_quads", 2), ("cull", 2)))
+    assert (img.view(np.uint32) == expected.view(np.uint32)).all()
+
+
 @pytest.mark.parametrize("path", CASE_FILES, ids=lambda p: os.path.basename(p)[:-4])
 def test_fp32_scan_kernel_matches_reference_shader_output(path, rt):
     """kernel 2: fp32 VALU filter + exact test (the variant without matrix cores) -- every golden case, bit for bit."""

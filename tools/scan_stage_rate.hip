@@ -105,7 +105,27 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
     MFMA(NB+16) MIN5(PB+16, 104) MX(101, 96, 97, 98) MX(102, 99, 100, 104) \
     MFMA(NB+32) MIN5(PB+32, 112) MX(103, 105, 106, 107) MX(109, 108, 112, 113) MX(110, 101, 102, 103) \
     MFMA(NB+48) MIN5(PB+48, 120) MX(111, 114, 115, 116) MX(117, 120, 121, 122) MX(118, 123, 124, 109) MX(119, 110, 111, 117) MX(119, 119, 118, 118) \
-    "v_cmp_lt_f32_e32 vcc, 0, v119\n\t"
+    "v_cmp_gt_f32_e32 vcc, 0, v119\n\t"       /* (inverted for the probe: its operands are positive, the branch must not be taken) */
+// 20: shared-edge tiles: 12 triangles per tile as 6 pairs of 5 rows per lane half (the shared edge's row serves both triangles, negated
+// for the second): 6 v_min3 (three with a negated operand), 3 v_max, 1 v_cmp per block
+#define EXAM_PAIRS(P, M) \
+    "v_min3_f32 v[" #M "+0], v[" #P "+0], v[" #P "+1], v[" #P "+2]\n\t" \
+    "v_min3_f32 v[" #M "+1], v[" #P "+3], v[" #P "+4], -v[" #P "+2]\n\t" \
+    "v_min3_f32 v[" #M "+2], v[" #P "+5], v[" #P "+6], v[" #P "+7]\n\t" \
+    "v_min3_f32 v[" #M "+3], v[" #P "+8], v[" #P "+9], -v[" #P "+7]\n\t" \
+    "v_min3_f32 v[" #M "+4], v[" #P "+10], v[" #P "+11], v[" #P "+12]\n\t" \
+    "v_min3_f32 v[" #M "+5], v[" #P "+13], v[" #P "+14], -v[" #P "+12]\n\t" \
+    "v_max3_f32 v[" #M "+6], v[" #M "+0], v[" #M "+1], v[" #M "+2]\n\t" \
+    "v_max3_f32 v[" #M "+7], v[" #M "+3], v[" #M "+4], v[" #M "+5]\n\t" \
+    "v_max_f32 v[" #M "+6], v[" #M "+6], v[" #M "+7]\n\t"
+#define CMP6(M, K) "v_cmp_nle_f32_e64 s[" #K ":" #K "+1], v[" #M "+6], %[th]\n\t"
+#define STAGE_PAIRS(NB, PB) \
+    MFMA(NB+0)  EXAM_PAIRS(PB+0, 96)  CMP6(96, 20) \
+    MFMA(NB+16) EXAM_PAIRS(PB+16, 104) CMP6(104, 22) \
+    MFMA(NB+32) EXAM_PAIRS(PB+32, 112) CMP6(112, 24) \
+    MFMA(NB+48) EXAM_PAIRS(PB+48, 120) CMP6(120, 26)
+// 21: the same with the shipped scalar spot (three s_or + compare + never-taken branch at the end of the stage)
+#define STAGE_PAIRS_SOR(NB, PB) STAGE_PAIRS(NB, PB) "s_or_b64 s[28:29], s[20:21], s[22:23]\n\t" SOR(24) SOR(26) SBR
 #define STAGE_VALU(NB, PB) \
     EXAMINE(PB+0, 96, th)  CMP(96, 20) EXAMINE(PB+16, 104, th) CMP(104, 22) EXAMINE(PB+32, 112, th) CMP(112, 24) EXAMINE(PB+48, 120, th) CMP(120, 26)
 #define STAGE_MFMA(NB, PB) MFMA(NB+0) MFMA(NB+16) MFMA(NB+32) MFMA(NB+48)
@@ -168,6 +188,8 @@ __global__ void __launch_bounds__(256 * WPS) __attribute__((amdgpu_waves_per_eu(
         else if (V == 17) RUN(STAGE_BRVCC);
         else if (V == 18) RUN(STAGE_BRMID);
         else if (V == 19) RUN(STAGE_FOLD);
+        else if (V == 20) RUN(STAGE_PAIRS);
+        else if (V == 21) RUN(STAGE_PAIRS_SOR);
         else if (V == 10) RUN2(STAGE_SORDEFER(192, 128, 20, 30) STAGE_SORDEFER(128, 192, 30, 20) "9:\n\t");
     }
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();
@@ -204,6 +226,8 @@ int main()
     run<16>("brscc", d, cus); run<17>("brvcc", d, cus); run<18>("brmid", d, cus); run<19>("fold", d, cus);
     run<0>("full", d, cus); run<13>("br", d, cus);
     // two waves per SIMD (256 registers each): does a second wave fill the ~40-cycle holes scalar instructions tear into the stream?
+    run<20>("pairs", d, cus); run<21>("pairs+sor", d, cus); run<9>("sorend", d, cus);
+    run<20, 2>("pairs x2", d, cus); run<21, 2>("pairs+sor x2", d, cus); run<19, 2>("fold x2", d, cus);
     run<0, 2>("full x2", d, cus); run<13, 2>("br x2", d, cus); run<8, 2>("sor x2", d, cus); run<9, 2>("sorend x2", d, cus); run<10, 2>("sordefer x2", d, cus);
     return 0;
 }
