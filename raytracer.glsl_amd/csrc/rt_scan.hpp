@@ -675,11 +675,14 @@ scan_solo_kernel(SceneView sc, WaveBuffers wb, MfView mf, uint32_t bounce, uint3
 }
 
 // ---- narrow phase: one lane per record (ray, first storage position << 5 | 5-bit survivor mask): exact reference-order test
-// (:243-249) of every marked triangle, atomicMin merge.  One block per wave region of the scan launch that preceded it.
+// (:243-249) of every marked triangle, atomicMin merge.  grid = (wave regions of the scan launch that preceded it, kNarrowSplit): the
+// blocks of a region take its records in turns of 256 -- the kernel is a chain of four dependent round trips per record, and with one
+// block per region its duration was that of the fullest region (three to four turns where the mean is under two).
+constexpr uint32_t kNarrowSplit = 4;
 __global__ void __launch_bounds__(256) narrow_phase_kernel(SceneView sc, WaveBuffers wb, MfView mf, uint32_t bounce, uint32_t n_regions)
 {
 #ifdef RT_SOLO_STAMPS
-    if (blockIdx.x == 0 && threadIdx.x == 0 && mf.dbg_log) {          // the slowest wave of the scan launch that just ended: summed per bounce
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && mf.dbg_log) {          // the slowest wave of the scan launch that just ended: summed per bounce
         unsigned long long *d = reinterpret_cast<unsigned long long *>(mf.dbg_log) + 16ull * bounce;
         d[13] += d[10]; d[10] = 0ull;
     }
@@ -689,7 +692,7 @@ __global__ void __launch_bounds__(256) narrow_phase_kernel(SceneView sc, WaveBuf
     for (uint32_t r = blockIdx.x; r < n_regions; r += gridDim.x) {
         const uint32_t n = min(wb.cand_counts[r], wb.cand_region);
         const uint2 *cand = wb.cand + (size_t)r * wb.cand_region;
-        for (uint32_t i = threadIdx.x; i < n; i += 256u) {
+        for (uint32_t i = blockIdx.y * 256u + threadIdx.x; i < n; i += 256u * gridDim.y) {
             const uint2 c = cand[i];
             uint32_t um = c.y & 31u;
             const uint32_t pos5 = c.y >> 5;
