@@ -230,8 +230,9 @@ def main():
                                  "frac_of_mfma_issue_peak": executed_per_launch / avg_launch_s / (n_simd * clk / 32.0),
                                  "note": "matrix instructions actually issued: the algorithmic figures above count every ray x triangle test the reference "
                                          "performs, including those a wave skips because all of its rays are certified rejections (packet culling)"},
-                    "note": "dominant kernel launch = packet bounds (culled bounces) + scan + narrow phase, timed together.  bound = matrix/vector issue of one SIMD port: 32 cycles of matrix pipe per product, 44 cycles of issue (MFMA 8 + 9 VALU x 4) measured "
-                            "for the bare instruction stream (tools/scan_stage_rate.hip); cycles are counted at the nominal 2.4 GHz, the chip runs this loop at ~2.0-2.1 GHz",
+                    "note": "dominant kernel launch = packet culling (culled bounces) + scan + narrow phase, timed together.  bound = matrix/vector issue of a SIMD: 32 cycles of matrix pipe per product; 44 cycles of issue "
+                            "(MFMA 8 + 9 VALU x 4) measured for the bare instruction stream of one wave, 33 with two waves per SIMD, 38-40 with the loop's scalar instructions (tools/scan_stage_rate.hip); cycles are counted at the "
+                            "nominal 2.4 GHz, the chip runs the two-wave loop at ~1.7 GHz",
                     "hbm": hbm}
             compute = {"pipe": "bf16 MFMA broad phase + fp32 VALU examination (one issue port per SIMD)", "algorithmic_tflops": tflops, "flop_per_test": 36,
                        "gtests_per_s": gtests, "scan_share_of_frame": scan_ms / max(frame_ms, 1e-9)}
