@@ -337,14 +337,11 @@ scan_solo_kernel(SceneView sc, WaveBuffers wb, MfView mf, uint32_t bounce, uint3
     const unsigned long long ts_wave_begin = RT_STAMP_NOW();
     unsigned long long tt_stage = 0, tt_rays = 0, tt_group = 0, tt_steady = 0, tt_park = 0, tt_flush = 0, tt_iters = 0, tt_culled = 0, tt_culled_n = 0, tt_tiles = 0;
 #endif
-    // A wave of this kernel must have its SIMD to itself.  With one wave per SIMD the kernel needs ~340 of the SIMD's 512 registers, and
-    // waves of OTHER kernels (another context's shading, ray generation ...) used to move in beside it: three contexts rendering on one
-    // device then produced, in 10-40 % of the runs, 16 wrong pixels -- always queue slots 48..63 of a 64-slot block, i.e. lanes 48..63 of
-    // one wave of a lane-per-slot kernel -- while the scan's own survivor counts stayed exact (tools/diagnostics/flaky_multi.py; the
-    // fault was in every build since round 1 and is the same one that made round 1's three-waves-per-SIMD variant lose survivors).
-    // Claiming the whole register file (two waves per SIMD: 2 x 256, one wave: 512) keeps everything else off the SIMD: 0 wrong images
-    // in 240 runs.  What exactly a co-resident wave suffers is not established (tools/coresident_probe.hip does not reproduce it with
-    // synthetic victims); DESIGN.md 5.2.
+    // With one wave per SIMD the wave claims the whole register file of its SIMD (as two waves do: 2 x 256), so that nothing else runs
+    // beside it and the compiler has AGPRs to spare instead of spilling.  History: DESIGN.md 5.2 -- builds whose one-wave scan used ~360
+    // registers, kept prefetched rays in AGPRs and spilled four values lost 16 rays of a launch every few dozen runs when other
+    // path-tracing pipelines ran on the device at the same time; the build with this line went 0 of 240 where its predecessor went
+    // 19 of 120 on the same box.  Why is not established.
     if constexpr (W == 1) asm volatile("" ::: "a255");
     const uint32_t n_rays = wb.counts[bounce], n_gran = (n_rays + 127u) >> 7;
     const RayQueue qin = (bounce & 1u) ? wb.q[1] : wb.q[0];
