@@ -1,11 +1,11 @@
 // coresident_probe.hip -- what happens to a wave that shares a SIMD with the kernel-4 instruction stream?
 //
-// Finding that prompted it (round 2, tools/diagnostics/flaky_multi.py): three contexts rendering on ONE device produced, in 10-40 % of
-// the runs, an image with 16 wrong pixels -- always queue slots 48..63 of a 64-slot block, i.e. lanes 48..63 of a wave of a kernel
-// whose lanes map to slots (ray generation, shading) -- while the scan's own counters (survivors, segments) stayed exact.  It happened
-// only with the one-wave-per-SIMD scan (340 of a SIMD's 512 registers: waves of OTHER kernels fit beside it), never with two scan waves
-// per SIMD (2 x 256: nothing fits beside them), never with the fp32 scan (no matrix instructions), and it vanished when the
-// one-wave scan claimed all 512 registers.  The victim is the OTHER wave.
+// Hypothesis that prompted it (round 2, tools/diagnostics/flaky_multi.py): three contexts rendering on ONE device produced, every few
+// dozen runs, an image with 16 wrong pixels -- always queue slots 48..63 of a 64-slot block -- while the scan's own counters stayed
+// exact, only with the one-wave-per-SIMD scan (which left room on its SIMDs for waves of other kernels), and not with a build that
+// claimed all 512 registers.  Is a wave that shares a SIMD with the matrix-instruction stream disturbed by it?
+// Result (profiles/r2_coresident_probe.txt): NO -- 0 wrong results in 1e9 checks per arm.  (The fault was later narrowed down to the
+// scan's own asynchronous ray prefetch: DESIGN.md 5.2, tools/mfma_load_return_probe.hip.)
 //
 // This probe isolates it on known operands: an aggressor kernel (one wave per SIMD, ~340 registers, 100 KB of LDS so that one block
 // owns a CU) runs a stream of its choice for ~100 ms; beside it, on a second stream, small victim kernels (24-64 registers) run
