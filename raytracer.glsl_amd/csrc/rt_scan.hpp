@@ -672,6 +672,10 @@ scan_solo_kernel(SceneView sc, WaveBuffers wb, MfView mf, uint32_t bounce, uint3
         atomicAdd(d + 9, tt_tiles);
         if (blockIdx.x == 0 && wave == 0) d[15] = (unsigned long long)gridDim.x * kWaves;
         atomicMax(d + 10, ts_end - ts_wave_begin);                // slowest wave of this launch: summed per bounce by the narrow phase
+        if (!kDyn && bounce < 16u) {                              // static launches: wave time per chunk (the block's only one)
+            unsigned long long *pc = reinterpret_cast<unsigned long long *>(mf.dbg_log) + 2048ull + (16ull * bounce) * 64ull * 2ull + 2ull * (c_first % 512u);
+            atomicAdd(pc, ts_end - ts_wave_begin); atomicAdd(pc + 1, 1ull);
+        }
         atomicAdd(d + 11, tt_culled); atomicAdd(d + 12, tt_culled_n);
     }
 #endif

@@ -300,6 +300,17 @@ extern "C" void rtgl_destroy(rtgl_context *ctx)
                         b, d[8], d[7], tot / d[8], 100.0 * d[1] / tot, 100.0 * d[2] / tot, 100.0 * d[3] / tot, 100.0 * d[4] / tot, 100.0 * d[5] / tot, 100.0 * d[6] / tot,
                         d[9] ? (double)d[4] / (double)d[9] : 0.0, (double)d[13] * (double)d[15] / (double)d[8], d[12], d[12] ? (double)d[11] / (double)d[12] : 0.0);
             }
+        // static launches: mean wave time per chunk, relative to the bounce's mean (what an uneven cost of the chunks loses)
+        std::vector<unsigned long long> pc(16 * 64 * 2 * 16);
+        if (hipMemcpy(pc.data(), reinterpret_cast<unsigned long long *>(ctx->d_dbg_log) + 2048, pc.size() * 8, hipMemcpyDeviceToHost) == hipSuccess)
+            for (int b = 0; b < 8; ++b) {
+                double tot = 0, cnt = 0; int nch = 0;
+                for (int c = 0; c < 64; ++c) { const unsigned long long *e = pc.data() + ((size_t)16 * b * 64 + c) * 2; if (e[1]) { tot += (double)e[0]; cnt += (double)e[1]; nch = c + 1; } }
+                if (cnt == 0) continue;
+                fprintf(stderr, "rtgl stamps bounce %2d: mean wave time per chunk / bounce mean:", b);
+                for (int c = 0; c < nch; ++c) { const unsigned long long *e = pc.data() + ((size_t)16 * b * 64 + c) * 2; fprintf(stderr, " %.2f", e[1] ? ((double)e[0] / (double)e[1]) / (tot / cnt) : 0.0); }
+                fprintf(stderr, "\n");
+            }
     }
 #endif
     void *ptrs[] = { ctx->d_spheres, ctx->d_materials, ctx->d_vertices, ctx->d_sphere_visits, ctx->d_edges, ctx->d_planes,
@@ -782,7 +793,7 @@ static int launch_intersect_solo(rtgl_context *ctx, const SceneView &sc, uint32_
     if (!dynamic) blocks = std::max(1u, std::min((est_gran + waves - 1u) / waves, std::max(1u, (uint32_t)ctx->n_cus / chunks))) * chunks;
     const size_t lds = std::max<size_t>(((size_t)chunk_quads * kMfQuadTiles + 4) * 1024, 96 * 1024);   // + the four rows read two trips ahead behind the last tile; > half of the CU's LDS with the static queue: one block per CU
 #ifdef RT_SOLO_STAMPS
-    if (!ctx->d_dbg_log) { HIPCHK(ctx, hipMalloc((void **)&ctx->d_dbg_log, (size_t)(2 + (2u << 22)) * 4)); HIPCHK(ctx, hipMemsetAsync(ctx->d_dbg_log, 0, 16 * 8 * 64, ctx->stream)); }
+    if (!ctx->d_dbg_log) { HIPCHK(ctx, hipMalloc((void **)&ctx->d_dbg_log, (size_t)(2 + (2u << 22)) * 4)); HIPCHK(ctx, hipMemsetAsync(ctx->d_dbg_log, 0, 2048 * 8 + 16 * 64 * 2 * 16 * 8, ctx->stream)); }
 #endif
     MfView mf{ctx->d_mf_groups, ctx->n_mf_groups, gq, n_quads, ctx->d_mf_A, ctx->d_dbg_log, ctx->d_mf_cull, ctx->d_mf_order};
     if (!ctx->solo_attr_set) {
