@@ -67,6 +67,8 @@ struct MfView {
     const uint4 *A;
     uint32_t *dbg_log;       // diagnostics only
     const MfCull *cull;      // one record per quad (packet culling)
+    const TriEdges *edges_s; const TriPlane *planes_s;   // the exact test's records in STORAGE order (copies of SceneView's, gathered at
+                             // upload): the narrow phase reads them by storage position, one dependent round trip less than through `order`
     const uint32_t *order;   // storage position -> visit index.  Triangles are stored in Morton order of their centroids
                              // so that the triangles of a group are neighbours (tight local bounds); hits are merged by VISIT
                              // index, so the reference's first-visited-wins tie rule (:349) is unaffected by the reordering
@@ -149,6 +151,14 @@ __global__ void __launch_bounds__(64) prepare_mfma_kernel(const float4 *__restri
     G.E = bad ? nanv : E * 1.001f; G.Ml = bad ? nanv : Ml * 1.001f; G.Pw = bad ? nanv : Pw * 1.001f;   // NaN bounds: nothing is ever rejected
     G.P = bad ? nanv : P * 1.001f; G.pad1 = 0.0f;
     groups[g] = G;
+}
+
+// storage-ordered copies of the exact test's triangle records
+__global__ void __launch_bounds__(256) gather_storage_order_kernel(const TriEdges *__restrict__ edges, const TriPlane *__restrict__ planes, const uint32_t *__restrict__ order,
+                                                                   uint32_t n, TriEdges *__restrict__ edges_s, TriPlane *__restrict__ planes_s)
+{
+    const uint32_t pos = blockIdx.x * 256u + threadIdx.x;
+    if (pos < n) { const uint32_t v = order[pos]; edges_s[pos] = edges[v]; planes_s[pos] = planes[v]; }
 }
 
 // ---- per ray (constant over the scan) and per (ray, group) quantities ------------------------------------------

@@ -1,26 +1,26 @@
-// rt_scan.hpp -- kernel variant 4 (default): the bf16 matrix-core broad phase of rt_mfma.hpp with ONE wave per SIMD and a
-// hand-ordered instruction stream.
+// rt_scan.hpp -- kernel variant 4 (default): the bf16 matrix-core broad phase of rt_mfma.hpp as a hand-ordered instruction stream, with
+// one or two waves per SIMD, plus the kernels around it (packet culling, work items, narrow phase).
 //
-// The broad phase of find_closest_mesh (:331-361) is the same contraction as in rt_mfma.hpp (same A tiles, same B operand,
-// same threshold, same margin proof): F~[edge row][ray] per (tile of 10 triangles, set of 32 rays) from ONE
-// v_mfma_f32_32x32x16_bf16, then "does any triangle of this lane survive" = 5 v_min3 + 2 v_max3 + 1 v_cmp on the 16 results.
-// What this file changes is the schedule.  With one wave on a SIMD nothing else fills a stall, so the order of the wave's
-// own instructions decides the speed (MI355X_MICROARCH.md: an MFMA occupies the matrix pipe for 32 cycles but holds the
-// vector issue port for 8 only; a VALU instruction costs 4):
+// The broad phase of find_closest_mesh (:331-361) is the contraction described in rt_mfma.hpp (A tiles, B operand, threshold, margin
+// proof): F~[edge row][ray] per (tile of 10 triangles, set of 32 rays) from ONE v_mfma_f32_32x32x16_bf16, then "does any triangle of
+// this lane survive" = 5 v_min3 + 2 v_max3 + 1 v_cmp on the 16 results.  What this file adds is the schedule.  An MFMA occupies the
+// matrix pipe for 32 cycles but holds the vector issue port for 8 only; a VALU instruction costs a wave 4 (MI355X_MICROARCH.md):
 //
 //     tile t:   mfma  X0 <- A_t B_0     8 VALU examining Y0 (tile t-1, set 0)
 //               mfma  X1 <- A_t B_1     8 VALU examining Y1
-//               ...                      (S sets; then ONE scalar branch on "any survivor in tile t-1")
+//               ...                      (4 ray sets; then ONE group of scalar instructions per TWO tiles)
 //     tile t+1: the same with X and Y swapped
 //
-// i.e. every examination reads an accumulator whose matrix instruction was issued S products (>= 160 cycles) earlier, and
-// every matrix instruction is followed by exactly the 8 vector instructions that fit beside it.  The compiler's own order
-// for the same source was "S products back to back, then 8 S VALU" (nothing overlaps: 125 cycles per product measured in
-// round 1); the order above is imposed with __builtin_amdgcn_sched_group_barrier and verified in the ISA (make asm).
+// i.e. every examination reads an accumulator whose matrix instruction was issued 4 products (>= 160 cycles) earlier, and every
+// matrix instruction is followed by exactly the vector instructions that fit beside it.  The compiler's own order for the same source
+// was "4 products back to back, then 32 VALU" (nothing overlaps: 125 cycles per product in round 1); here the order is written out in
+// inline asm whose operands are bound to physical registers (the compiler sees ordinary dataflow and keeps out of the way).
 //
-// Also per block: the chunk's A tiles live in LDS (loaded once, blocks are persistent over ray blocks); the rays of the NEXT
-// ray block are fetched while the current one is scanned; survivors go to a per-wave LDS queue and from there to the global
-// candidate buffer of the narrow-phase kernel (64-bit counter; what does not fit is tested in place).
+// Around the stream: a block stages the A tiles of a chunk of <= 32 quads in LDS and its waves work through (granule of 128 rays,
+// chunk) items -- handed out in fixed turns or claimed from counters (scan_solo_kernel below); survivors go to a per-wave LDS queue
+// and from there, as dense records, to the wave's own region of the candidate buffer for narrow_phase_kernel (what does not fit is
+// tested in place); packet_cull_kernel certifies, per granule and quad, that every ray misses every triangle by the reference's own
+// arithmetic (rt_mfma.hpp, MfCull) so that the scan can skip the quad.
 #pragma once
 #include <type_traits>
 #include "rt_mfma.hpp"
@@ -144,6 +144,17 @@ __global__ void __launch_bounds__(256) packet_cull_kernel(WaveBuffers wb, const 
             }
         }
     }
+}
+
+// exact reference-order test (:243-249) of the triangle at storage position `pos` for the ray in queue slot `slot`; the hit key carries the
+// VISIT index (the reference's first-visited-wins tie rule, :349), read beside the records, not before them
+__device__ __forceinline__ void exact_and_merge_at(const MfView &mf, const RayQueue &qin, unsigned long long *best, uint32_t slot, uint32_t pos)
+{
+    const float4 a = qin.a[slot], b = qin.b[slot];
+    const uint32_t v = mf.order[pos];
+    TriRay tr; tr.o = mk(a.x, a.y, a.z); tr.d = mk(a.w, b.x, b.y); tr.cv = cross3(tr.d, tr.o); tr.ncv = tr.nd = 0.0f;
+    const float t = tri_exact(mf.edges_s[pos], mf.planes_s[pos], tr);
+    if (kEps < t && t < kInf) atomicMin(&best[slot], ((unsigned long long)__float_as_uint(t) << 32) | v);
 }
 
 constexpr int kSoloSets = 4;                                      // 32-ray sets per wave: 512 rays per block of four waves
@@ -531,7 +542,7 @@ scan_solo_kernel(SceneView sc, WaveBuffers wb, MfView mf, uint32_t bounce, uint3
                             while (um) {
                                 const uint32_t pos = pos5 + (uint32_t)__builtin_ctz(um);
                                 um &= um - 1u;
-                                if (pos < v_chunk_end) exact_and_merge(sc, qin, best, slot, mf.order[pos]);
+                                if (pos < v_chunk_end) exact_and_merge_at(mf, qin, best, slot, pos);
                             }
                     }
                     appended += (unsigned long long)__popcll(m);
@@ -704,16 +715,18 @@ __global__ void __launch_bounds__(256) narrow_phase_kernel(SceneView sc, WaveBuf
     const RayQueue qin = (bounce & 1u) ? wb.q[1] : wb.q[0];
     unsigned long long *best = (bounce & 1u) ? wb.best[1] : wb.best[0];
     for (uint32_t r = blockIdx.x; r < n_regions; r += gridDim.x) {
-        const uint32_t n = min(wb.cand_counts[r], wb.cand_region);
         const uint2 *cand = wb.cand + (size_t)r * wb.cand_region;
-        for (uint32_t i = blockIdx.y * 256u + threadIdx.x; i < n; i += 256u * gridDim.y) {
-            const uint2 c = cand[i];
+        const uint32_t i0 = blockIdx.y * 256u + threadIdx.x;
+        uint2 c = i0 < wb.cand_region ? cand[i0] : make_uint2(0u, 0u);      // (read together with the count: one round trip less)
+        const uint32_t n = min(wb.cand_counts[r], wb.cand_region);
+        for (uint32_t i = i0; i < n; i += 256u * gridDim.y) {
+            if (i != i0) c = cand[i];
             uint32_t um = c.y & 31u;
             const uint32_t pos5 = c.y >> 5;
             while (um) {
                 const uint32_t pos = pos5 + (uint32_t)__builtin_ctz(um);
                 um &= um - 1u;
-                if (pos < sc.n_tri_visits) exact_and_merge(sc, qin, best, c.x, mf.order[pos]);     // (padding rows behind the last triangle)
+                if (pos < sc.n_tri_visits) exact_and_merge_at(mf, qin, best, c.x, pos);     // (padding rows behind the last triangle)
             }
         }
     }

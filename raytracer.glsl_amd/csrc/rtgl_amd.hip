@@ -170,6 +170,7 @@ struct rtgl_context {
     float4 *d_vertices = nullptr;
     uint32_t *d_sphere_visits = nullptr; uint32_t n_sphere_visits = 0;
     TriEdges *d_edges = nullptr; TriPlane *d_planes = nullptr; uint32_t n_tri_visits = 0;
+    TriEdges *d_edges_s = nullptr; TriPlane *d_planes_s = nullptr;          // ... in the storage order of the matrix-core scan (narrow phase)
     uint8_t *d_env = nullptr; int env_w = 0, env_h = 0, env_c = 0, env_faces = 0;
     float4 *d_image_own = nullptr, *d_image = nullptr;
     uint4 *d_rng = nullptr;
@@ -315,7 +316,7 @@ extern "C" void rtgl_destroy(rtgl_context *ctx)
 #endif
     void *ptrs[] = { ctx->d_spheres, ctx->d_materials, ctx->d_vertices, ctx->d_sphere_visits, ctx->d_edges, ctx->d_planes,
                      ctx->d_env, ctx->d_image_own, ctx->d_rng, ctx->d_counters, ctx->d_u8, ctx->d_group_bounds, ctx->d_wave, ctx->d_counts, ctx->d_mf_groups, ctx->d_mf_A, ctx->d_mf_order,
-                     ctx->d_dbg_log, ctx->d_cand, ctx->d_mf_cull, ctx->d_keep, ctx->d_items, ctx->d_sched };
+                     ctx->d_dbg_log, ctx->d_cand, ctx->d_mf_cull, ctx->d_keep, ctx->d_items, ctx->d_sched, ctx->d_edges_s, ctx->d_planes_s };
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (hipEvent_t e : ctx->kev) (void)hipEventDestroy(e);
     if (ctx->h_counts) (void)hipHostFree(ctx->h_counts);
@@ -590,6 +591,8 @@ static int rebuild_triangles(rtgl_context *ctx)
         if (ctx->d_mf_A) { HIPCHK(ctx, hipFree(ctx->d_mf_A)); ctx->d_mf_A = nullptr; }
         if (ctx->d_mf_order) { HIPCHK(ctx, hipFree(ctx->d_mf_order)); ctx->d_mf_order = nullptr; }
         if (ctx->d_mf_cull) { HIPCHK(ctx, hipFree(ctx->d_mf_cull)); ctx->d_mf_cull = nullptr; }
+        if (ctx->d_edges_s) { HIPCHK(ctx, hipFree(ctx->d_edges_s)); ctx->d_edges_s = nullptr; }
+        if (ctx->d_planes_s) { HIPCHK(ctx, hipFree(ctx->d_planes_s)); ctx->d_planes_s = nullptr; }
         // quads sharing one local origin: 32 (= a chunk: one ray set-up per work item of the scan) unless the caller chose.  Smaller
         // groups have tighter bounds and fewer survivors (C4: 89 M per frame at 8 quads against 111 M at 32), but every group of a
         // chunk costs the scan a ray set-up and a pipeline fill of its own: 28.4 against 30.0 Mpaths/s
@@ -599,6 +602,10 @@ static int rebuild_triangles(rtgl_context *ctx)
         const std::vector<uint32_t> order = morton_order(ctx, visit_tri);
         HIPCHK(ctx, hipMalloc((void **)&ctx->d_mf_order, order.size() * 4));
         HIPCHK(ctx, hipMemcpyAsync(ctx->d_mf_order, order.data(), order.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(ctx, hipMalloc((void **)&ctx->d_edges_s, (size_t)ctx->n_tri_visits * sizeof(TriEdges)));
+        HIPCHK(ctx, hipMalloc((void **)&ctx->d_planes_s, (size_t)ctx->n_tri_visits * sizeof(TriPlane)));
+        hipLaunchKernelGGL(gather_storage_order_kernel, dim3((ctx->n_tri_visits + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_edges, ctx->d_planes, ctx->d_mf_order,
+                           ctx->n_tri_visits, ctx->d_edges_s, ctx->d_planes_s);
         HIPCHK(ctx, hipMalloc((void **)&ctx->d_mf_groups, (size_t)ctx->n_mf_groups * sizeof(MfGroup)));
         const size_t a_bytes = ((size_t)ctx->n_mf_groups * ctx->mf_group_quads + 1) * kMfQuadTiles * 64 * sizeof(uint4);   // two K panels per tile; + one zero quad
         if (a_bytes > 0xFFFF0000ull) return fail(ctx, RTGL_ERR_INVALID, "mesh too large for the 32-bit tile offsets of the matrix-core scan");
@@ -795,7 +802,7 @@ static int launch_intersect_solo(rtgl_context *ctx, const SceneView &sc, uint32_
 #ifdef RT_SOLO_STAMPS
     if (!ctx->d_dbg_log) { HIPCHK(ctx, hipMalloc((void **)&ctx->d_dbg_log, (size_t)(2 + (2u << 22)) * 4)); HIPCHK(ctx, hipMemsetAsync(ctx->d_dbg_log, 0, 2048 * 8 + 16 * 64 * 2 * 16 * 8, ctx->stream)); }
 #endif
-    MfView mf{ctx->d_mf_groups, ctx->n_mf_groups, gq, n_quads, ctx->d_mf_A, ctx->d_dbg_log, ctx->d_mf_cull, ctx->d_mf_order};
+    MfView mf{ctx->d_mf_groups, ctx->n_mf_groups, gq, n_quads, ctx->d_mf_A, ctx->d_dbg_log, ctx->d_mf_cull, ctx->d_edges_s, ctx->d_planes_s, ctx->d_mf_order};
     if (!ctx->solo_attr_set) {
         // allow the whole LDS of a CU (160 KB) minus the kernel's static share as dynamic shared memory.  The attribute belongs to the
         // (function, device) pair, so it is raised once per context -- a context is bound to one device -- not once per process.
