@@ -357,7 +357,9 @@ scan_solo_kernel(SceneView sc, WaveBuffers wb, MfView mf, uint32_t bounce, uint3
     const uint32_t n_rays = wb.counts[bounce], n_gran = (n_rays + 127u) >> 7;
     const RayQueue qin = (bounce & 1u) ? wb.q[1] : wb.q[0];
     unsigned long long *best = (bounce & 1u) ? wb.best[1] : wb.best[0];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, col = lane & 31, half = lane >> 5;
+    // (`wave` through readfirstlane: the compiler cannot know that threadIdx.x >> 6 is the same in all lanes, and everything the item loop
+    // derives from it -- item index, granule, keep bits, loop control -- would live in vector registers under EXEC masks)
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), col = lane & 31, half = lane >> 5;
     // only quads that hold triangles; the padding rows inside the last one carry a -3e38 bias and never survive
     const uint32_t real_quads = min(mf.n_quads, (sc.n_tri_visits + kMfQuadTris - 1u) / kMfQuadTris);
     // survivors of this wave go to ITS region of the candidate buffer: no atomic, no round trip the single wave of a SIMD would wait for
