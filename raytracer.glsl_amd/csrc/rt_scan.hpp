@@ -425,7 +425,7 @@ scan_solo_kernel(SceneView sc, WaveBuffers wb, MfView mf, uint32_t bounce, uint3
                 if (lane == 0) lds_pick = dist == 0xFFFFFFFFu ? 0xFFFFFFFFu : (c_from + dist) % n_chunks;
             }
             __syncthreads();
-            c = lds_pick;
+            c = __builtin_amdgcn_readfirstlane(lds_pick);            // (uniform, and the compiler should know)
             if (c == 0xFFFFFFFFu) break;
         }
         c_from = (c + 1u) % n_chunks;
