@@ -148,7 +148,7 @@ int rtgl_read_rng_state(rtgl_context *ctx, uint32_t *xyzw);    /* per local pixe
 /* keys: "kernel" (enum above), "wf_rays" (rays per lane 1/2/4/8), "wf_mode" (0 scalar-fed, 1 LDS tiles),
  * "wf_chunk" (triangles per work item of the split intersect kernel, multiple of 64), "wf_early" (leading bounces
  * that use the wave-level edge short circuit), "wf_packed" (v_pk_fma_f32 ray pairs on/off), "mf_chunk_quads" (kernel 4: 40-triangle quads
- * per work item = per block's LDS-resident chunk, 1..32), "scan_waves" (waves per SIMD of the kernel-4 scan: 0 chosen per launch (default), 1, 2), "scan_dynamic" (work distribution of the kernel-4 scan: 0 chosen by the mesh (default), 1 static, 2 dynamic), "cull" (packet culling of whole quads per wave:
+ * per work item = per block's LDS-resident chunk, 1..32), "scan_waves" (waves per SIMD of the kernel-4 scan: 0 default (= 2), 1, 2), "scan_dynamic" (work distribution of the kernel-4 scan: 0 chosen by the mesh (default), 1 static, 2 dynamic), "cull" (packet culling of whole quads per wave:
  * 0 off, 1 on the camera-ray bounce (default), 2 on every bounce), "mf_group_quads" (quads
  * sharing one local origin: a power of two up to 64; changing it rebuilds the broad-phase data at the next frame),
  * "rng_state", "counters", "kernel_timing" (0 off; N > 0: every N-th frame since the last rtgl_timing_reset carries HIP

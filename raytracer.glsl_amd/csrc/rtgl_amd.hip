@@ -775,13 +775,11 @@ static int launch_intersect_solo(rtgl_context *ctx, const SceneView &sc, uint32_
     const uint32_t gq = ctx->mf_group_quads, n_quads = ctx->n_mf_groups * gq;
     const uint32_t real_quads = std::min(n_quads, (ctx->n_tri_visits + (uint32_t)kMfQuadTris - 1) / (uint32_t)kMfQuadTris);
     using Cfg = SoloCfg;
-    // Two waves per SIMD run the steady stream 1.5x faster (47 against 70 cycles per product), but a block then takes 1,024 rays per
-    // trip: a bounce with fewer than four (ray block x chunk) items per CU is better off with one wave per SIMD and 512-ray blocks
-    // (measured on C2: from ~130k rays down).  "scan_waves" = 0 chooses per launch, 1 / 2 force.
+    // Two waves per SIMD run the steady stream 1.5x faster (47 against 70 cycles per product).  Until the item loop moved into scalar
+    // registers small launches were better off with one wave per SIMD (half as many rays per block); measured since: two waves win or tie
+    // everywhere (C2 3.394 against 3.434 ms, a rank of eight 0.686 against 0.713 ms).  "scan_waves" = 0 / 2: two, 1: one.
     const uint32_t est = estimate_rays(ctx, n0, bounce);
-    const uint32_t base_chunks = (real_quads + std::min((uint32_t)ctx->opt_mf_chunk_quads, std::max(real_quads, 1u)) - 1) / std::min((uint32_t)ctx->opt_mf_chunk_quads, std::max(real_quads, 1u));
-    const uint32_t W = ctx->opt_scan_waves ? (uint32_t)ctx->opt_scan_waves
-                                           : (((uint64_t)((est + 8u * Cfg::kRaysPerWave - 1u) / (8u * Cfg::kRaysPerWave)) * base_chunks >= 4ull * (uint32_t)ctx->n_cus) ? 2u : 1u);
+    const uint32_t W = ctx->opt_scan_waves == 1 ? 1u : 2u;
     const uint32_t waves = 4u * W;
     const uint32_t est_gran = (est + Cfg::kRaysPerWave - 1u) / Cfg::kRaysPerWave;
     // A launch has (granules x chunks) work items for its waves, claimed dynamically (rt_scan.hpp).  Late bounces (and every bounce of a
