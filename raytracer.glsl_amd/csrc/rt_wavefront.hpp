@@ -100,8 +100,11 @@ __device__ __forceinline__ void finish_path(const FrameParams &P, const ImageVie
 
 // ---- queue 0 ---------------------------------------------------------------------------------------
 // sample 0: camera rays from scratch.  sample > 0: same camera ray, RNG continued (:556-559).
-__global__ void __launch_bounds__(256) generate_rays_kernel(FrameParams P, ImageView im, WaveBuffers wb, uint32_t sample, uint32_t n0, Counters *counters)
+__global__ void __launch_bounds__(256) generate_rays_kernel(FrameParams P, ImageView im, WaveBuffers wb, uint32_t sample, uint32_t n0, Counters *counters, uint32_t n_counts)
 {
+    // the ray counts of the bounces (and the word behind them) start at zero: cleared here rather than by a memset launch of their own
+    // (n_counts = 0: the host has done it); nothing touches them before the first shade kernel
+    if (blockIdx.x == 0 && threadIdx.x < n_counts && threadIdx.x > 0u) wb.counts[threadIdx.x] = 0u;
     // queue order = 8x8 pixel blocks, row-major over blocks: neighbouring lanes start as neighbouring pixels
     const uint32_t idx = blockIdx.x * 256u + threadIdx.x;
     if (idx >= n0) return;

@@ -862,11 +862,12 @@ static int launch_wavefront(rtgl_context *ctx, const SceneView &sc, const FrameP
         if (!ctx->cand_fixed && peak > ctx->cand_region_pairs) ctx->cand_region_target = (uint32_t)std::min<uint64_t>((uint64_t)peak + peak / 4, 0xFFFFFFF0u);
     }
     for (uint32_t s = 0; s < P.samples; ++s) {
-        HIPCHK(ctx, hipMemsetAsync(ctx->d_counts, 0, counts_bytes(ctx->counts_capacity), ctx->stream));
+        const uint32_t n_counts = ctx->counts_capacity + 1u <= 256u ? ctx->counts_capacity + 1u : 0u;      // cleared by generate_rays_kernel's first block
+        if (!n_counts) HIPCHK(ctx, hipMemsetAsync(ctx->d_counts, 0, counts_bytes(ctx->counts_capacity), ctx->stream));
         if (ctx->opt_kernel == RTGL_KERNEL_WAVEFRONT_MFMA_SOLO && ctx->d_sched && solo_dynamic(ctx))       // the scan launches' work counters (rt_scan.hpp)
             HIPCHK(ctx, hipMemsetAsync(ctx->d_sched, 0, (size_t)(P.max_bounce + 2) * ctx->wb.sched_stride * sizeof(uint32_t), ctx->stream));
         hipLaunchKernelGGL(generate_rays_kernel, gen_grid, dim3(256), 0, ctx->stream, P, im, ctx->wb, s, n0,
-                           ctx->opt_counters ? ctx->d_counters : (Counters *)nullptr);
+                           ctx->opt_counters ? ctx->d_counters : (Counters *)nullptr, n_counts);
         for (uint32_t b = 0; b < P.max_bounce; ++b) {
             const int key = ctx->opt_wf_mode * 10 + ctx->opt_wf_rays;
             if (ctx->opt_kernel == RTGL_KERNEL_WAVEFRONT_SPLIT || ctx->opt_kernel == RTGL_KERNEL_WAVEFRONT_MFMA_SOLO) {
