@@ -1221,7 +1221,7 @@ extern "C" int rtgl_set_option(rtgl_context *ctx, const char *key, int value)
         if (value < 1 || (uint32_t)value > kMfMaxChunkQuads) return fail(ctx, RTGL_ERR_INVALID, "mf_chunk_quads must be in [1, 32]");
         ctx->opt_mf_chunk_quads = value;
     } else if (!strcmp(key, "scan_waves")) {
-        if (value < 0 || value > 2) return fail(ctx, RTGL_ERR_INVALID, "scan_waves (waves per SIMD of the kernel-4 scan) must be 0 (chosen per launch), 1 or 2");
+        if (value < 0 || value > 2) return fail(ctx, RTGL_ERR_INVALID, "scan_waves (waves per SIMD of the kernel-4 scan) must be 0 (default: two), 1 or 2");
         ctx->opt_scan_waves = value;
     } else if (!strcmp(key, "scan_dynamic")) {
         if (value < 0 || value > 2) return fail(ctx, RTGL_ERR_INVALID, "scan_dynamic must be 0 (chosen by the mesh), 1 (static) or 2 (dynamic)");
