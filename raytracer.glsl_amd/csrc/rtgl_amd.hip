@@ -7,6 +7,8 @@
 #include <cstring>
 #include <string>
 #include <vector>
+#include <map>
+#include <mutex>
 
 #include "../../include/rtgl_amd.h"
 #include "rt_device.hpp"
@@ -151,7 +153,7 @@ struct rtgl_context {
     int device = 0;
     int width = 0, height = 0;
     int rank = 0, world = 1, strip_rows = 8, local_rows = 0;
-    hipStream_t own_stream = nullptr, stream = nullptr;
+    hipStream_t own_stream = nullptr, stream = nullptr; bool own_stream_shared = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
     // kernel_timing: events since the last rtgl_timing_reset.  Per frame: [frame begin, (launch begin, launch end)*, frame end]
@@ -239,6 +241,37 @@ static int local_rows_for(int height, int rank, int world, int strip_rows)
     return rows;
 }
 
+// Every context of a process on one device submits to ONE stream (unless the caller binds its own with rtgl_set_stream): the kernels
+// of different contexts then never run beside each other.  Several path-tracing pipelines running CONCURRENTLY on a device have
+// produced wrong frames (16 rays of a launch scanning stale data; DESIGN.md 5.2 -- rare with the shipped kernels, cause not
+// established); a single pipeline at a time never has.  RTGL_AMD_PRIVATE_STREAMS=1 restores one stream per context (diagnostics:
+// tools/diagnostics/flaky_tiled.py).
+static std::mutex g_stream_mutex;
+static std::map<int, std::pair<hipStream_t, int>> g_device_streams;
+static hipError_t acquire_device_stream(int device, hipStream_t *out, bool *shared)
+{
+    const char *priv = getenv("RTGL_AMD_PRIVATE_STREAMS");
+    if (priv && atoi(priv) != 0) { *shared = false; return hipStreamCreateWithFlags(out, hipStreamNonBlocking); }
+    std::lock_guard<std::mutex> lock(g_stream_mutex);
+    auto it = g_device_streams.find(device);
+    if (it == g_device_streams.end()) {
+        hipStream_t st = nullptr;
+        const hipError_t e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+        if (e != hipSuccess) return e;
+        it = g_device_streams.emplace(device, std::make_pair(st, 0)).first;
+    }
+    it->second.second++;
+    *out = it->second.first; *shared = true;
+    return hipSuccess;
+}
+static void release_device_stream(int device, hipStream_t st, bool shared)
+{
+    if (!shared) { (void)hipStreamDestroy(st); return; }
+    std::lock_guard<std::mutex> lock(g_stream_mutex);
+    auto it = g_device_streams.find(device);
+    if (it != g_device_streams.end() && --it->second.second == 0) { (void)hipStreamDestroy(it->second.first); g_device_streams.erase(it); }
+}
+
 extern "C" int rtgl_create_tiled(rtgl_context **out, int width, int height, int device, int rank, int world, int strip_rows)
 {
     if (!out) return fail(nullptr, RTGL_ERR_INVALID, "out is NULL");
@@ -258,7 +291,7 @@ extern "C" int rtgl_create_tiled(rtgl_context **out, int width, int height, int 
     ctx->error = std::string(#expr) + ": " + hipGetErrorString(e_); return bail(RTGL_ERR_DEVICE); } } while (0)
     CCHK(hipSetDevice(device));
     { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) ctx->n_cus = prop.multiProcessorCount; }
-    CCHK(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
+    CCHK(acquire_device_stream(device, &ctx->own_stream, &ctx->own_stream_shared));
     ctx->stream = ctx->own_stream;
     CCHK(hipEventCreate(&ctx->ev0));
     CCHK(hipEventCreate(&ctx->ev1));
@@ -323,7 +356,7 @@ extern "C" void rtgl_destroy(rtgl_context *ctx)
     if (ctx->counts_ev) (void)hipEventDestroy(ctx->counts_ev);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
-    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    if (ctx->own_stream) release_device_stream(ctx->device, ctx->own_stream, ctx->own_stream_shared);
     delete ctx;
 }
 
@@ -351,11 +384,7 @@ extern "C" int rtgl_create_multi(rtgl_context **out, int width, int height, cons
         rtgl_context *part = nullptr;
         rc = rtgl_create_tiled(&part, width, height, devices[i], i, n_devices, strip_rows);
         if (rc) { const std::string msg = g_create_error; rtgl_destroy(ctx); g_create_error = msg; return rc; }
-        // Parts that share a device share a stream: their kernels never run beside each other.  (Independent contexts rendering
-        // CONCURRENTLY on one device are not safe with kernel 4 on the pool's MI355X boxes: every few hundred frames 16 rays of one
-        // launch lose their mesh hit -- DESIGN.md 5.2, tools/diagnostics/flaky_tiled.py.  Several GPUs, one context each, is the
-        // configuration this entry point exists for.)
-        for (int j = 0; j < i; ++j) if (devices[j] == devices[i]) { part->stream = ctx->parts[j]->stream; break; }
+        // (parts that share a device share its stream, like all contexts of the process: acquire_device_stream)
         ctx->parts.push_back(part);
         hipEvent_t ev = nullptr;
         (void)hipSetDevice(devices[i]);

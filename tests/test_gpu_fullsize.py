@@ -233,8 +233,8 @@ def test_multi_device_context_through_the_c_abi_matches_single_context(devices, 
 def test_three_contexts_sharing_one_device_repeat_the_reference_image(opts, rt):
     """Round 2 found that several kernel-4 pipelines rendering CONCURRENTLY on one device come back, every few dozen to few hundred
     runs, with 16 rays of one launch having lost their mesh hit (tools/diagnostics/flaky_tiled.py reproduces it with
-    independent contexts; the cause is not established).  Parts of rtgl_create_multi that share a device therefore share a stream:
-    their kernels never run beside each other.  25 repetitions per option set of exactly the scenario that used to fail in 10-40 % of
+    independent contexts on private streams; the cause is not established).  All contexts of a process on one device therefore share a
+    stream: their kernels never run beside each other.  25 repetitions per option set of exactly the scenario that used to fail in 10-40 % of
     the runs must all equal the fp32-scan reference bit for bit."""
     sc = rt.scenes
     W, H = 328, 204

@@ -1,6 +1,7 @@
 # repeats the small three-parts-on-one-device render (tests/test_gpu_fullsize.py: multi-device context) under several option sets and
 # reports where an image differs from the fp32-scan reference (rows / columns / values), if it ever does
 import sys, os, numpy as np
+os.environ.setdefault("RTGL_AMD_PRIVATE_STREAMS", "1")      # one stream per context, as before the contexts of a device shared one: this script is about concurrency
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import raytracer_glsl_amd as rt
 sc = rt.scenes

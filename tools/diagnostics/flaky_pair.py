@@ -1,6 +1,7 @@
 # two INDEPENDENT contexts rendering concurrently on one device (frames enqueued without waiting, then both waited for), one with the
 # one-wave-per-SIMD kernel-4 scan and one with another scan: whose image goes wrong?
 import sys, os, numpy as np
+os.environ.setdefault("RTGL_AMD_PRIVATE_STREAMS", "1")      # one stream per context, as before the contexts of a device shared one: this script is about concurrency
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import raytracer_glsl_amd as rt
 sc = rt.scenes

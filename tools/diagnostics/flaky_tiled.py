@@ -1,6 +1,7 @@
 # three INDEPENDENT tiled contexts (rank 0..2 of 3, 8-row strips) rendering concurrently on one device, no gather: does a rank's own
 # image go wrong?  (tools/diagnostics/flaky_multi.py is the same through rtgl_create_multi and its gather)
 import sys, os, numpy as np
+os.environ.setdefault("RTGL_AMD_PRIVATE_STREAMS", "1")      # one stream per context, as before the contexts of a device shared one: this script is about concurrency
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import raytracer_glsl_amd as rt
 sc = rt.scenes
