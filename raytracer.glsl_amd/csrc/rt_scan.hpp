@@ -139,8 +139,8 @@ __global__ void __launch_bounds__(256) packet_cull_kernel(WaveBuffers wb, const 
             const unsigned long long have = (n_quads - q0 >= 64u) ? ~0ull : ((1ull << (n_quads - q0)) - 1ull);
             const unsigned long long keep = ~(unsigned long long)__builtin_amdgcn_ballot_w64(skip) & have;
             if (lane == 0u) {
-                row[q0 >> 5] = (uint32_t)keep;
-                if ((q0 >> 5) + 1u < wb.keep_words) row[(q0 >> 5) + 1u] = (uint32_t)(keep >> 32);
+                store_through(row + (q0 >> 5), (uint32_t)keep);                     // (read by later kernels: rt_wavefront.hpp, store_through)
+                if ((q0 >> 5) + 1u < wb.keep_words) store_through(row + ((q0 >> 5) + 1u), (uint32_t)(keep >> 32));
             }
         }
     }
@@ -310,7 +310,7 @@ __global__ void __launch_bounds__(256) cull_items_kernel(WaveBuffers wb, uint32_
         uint32_t at = 0u;
         if (lane == 0u) at = atomicAdd(wb.item_counts + c, (uint32_t)__popcll(m));
         at = __builtin_amdgcn_readfirstlane(at) + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-        if (bits != 0u) wb.items[(size_t)c * wb.items_stride + at] = make_uint2(g, bits);
+        if (bits != 0u) store_through(reinterpret_cast<unsigned long long *>(wb.items + ((size_t)c * wb.items_stride + at)), (unsigned long long)g | ((unsigned long long)bits << 32));
     }
     if (kCount && culled) atomicAdd(&counters->culled_tests, culled);
 }
@@ -539,7 +539,7 @@ scan_solo_kernel(SceneView sc, WaveBuffers wb, MfView mf, uint32_t bounce, uint3
                     const unsigned long long at = appended + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
                     const uint32_t slot = wave_slot0 + (uint32_t)(s * 32) + (ln & 31u);
                     if (um != 0u) {
-                        if (at < (unsigned long long)wb.cand_region) cand[at] = make_uint2(slot, (pos5 << 5) | um);
+                        if (at < (unsigned long long)wb.cand_region) store_through(reinterpret_cast<unsigned long long *>(cand + at), (unsigned long long)slot | ((unsigned long long)((pos5 << 5) | um) << 32));
                         else
                             while (um) {
                                 const uint32_t pos = pos5 + (uint32_t)__builtin_ctz(um);
@@ -692,7 +692,7 @@ scan_solo_kernel(SceneView sc, WaveBuffers wb, MfView mf, uint32_t bounce, uint3
         atomicAdd(d + 11, tt_culled); atomicAdd(d + 12, tt_culled_n);
     }
 #endif
-    if (lane == 0) wb.cand_counts[region] = (uint32_t)(appended < (unsigned long long)wb.cand_region ? appended : (unsigned long long)wb.cand_region);
+    if (lane == 0) store_through(wb.cand_counts + region, (uint32_t)(appended < (unsigned long long)wb.cand_region ? appended : (unsigned long long)wb.cand_region));
     if (lane == 0 && appended > (unsigned long long)*wb.cand_peak) atomicMax(wb.cand_peak, (uint32_t)(appended < 0xFFFFFFF0ull ? appended : 0xFFFFFFF0ull));   // (racy pre-check: only saves atomics)
     if (kCount) {
         if (c_cand_lane) atomicAdd(&counters->candidates, c_cand_lane);

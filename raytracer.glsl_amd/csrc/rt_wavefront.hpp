@@ -60,13 +60,30 @@ struct WaveBuffers {
 
 struct PathState { f3 o, d, thr, rad; Rng rng; uint32_t pixel; };
 
+// Stores of data the NEXT kernels read (ray queues, hit keys): written through to memory (system scope) instead of left as dirty lines in
+// the L2 of whichever XCD the wave ran on.  MI355X has eight L2s; a line written by one kernel from XCD A and, a frame later, by the same
+// kernel from XCD B can be written back out of order if A's dirty copy is still around -- memory then falls back to the old value.  With
+// one pipeline on the device the block -> XCD mapping repeats from frame to frame and this does not happen; with several pipelines
+// dispatching at once it did: 16 queue slots (256 bytes) of a frame reverting to the previous frame's rays after ray generation had
+// verifiably written the new ones (tools/diagnostics/flaky_tiled.py: 49 and 22 wrong images of 600 with ordinary stores,
+// 1 and 3 -- of another kind -- with these, same box, alternating).
+// (inline asm: the compiler's hazard recogniser does not see these stores, so the wait states a store of more than 8 bytes needs before a
+// vector instruction may overwrite its data registers are part of the statement)
+typedef float rt_f4v __attribute__((ext_vector_type(4)));
+typedef uint32_t rt_u4v __attribute__((ext_vector_type(4)));
+typedef uint32_t rt_u2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void store_through(float4 *p, float x, float y, float z, float w) { const rt_f4v v = {x, y, z, w}; asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" :: "v"(p), "v"(v) : "memory"); }
+__device__ __forceinline__ void store_through(uint4 *p, uint32_t x, uint32_t y, uint32_t z, uint32_t w) { const rt_u4v v = {x, y, z, w}; asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" :: "v"(p), "v"(v) : "memory"); }
+__device__ __forceinline__ void store_through(uint32_t *p, uint32_t x) { asm volatile("global_store_dword %0, %1, off sc0 sc1" :: "v"(p), "v"(x) : "memory"); }
+__device__ __forceinline__ void store_through(unsigned long long *p, unsigned long long x) { const rt_u2v v = {(uint32_t)x, (uint32_t)(x >> 32)}; asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1\n\ts_nop 1" :: "v"(p), "v"(v) : "memory"); }
+
 __device__ __forceinline__ void store_ray(const RayQueue &q, uint32_t slot, const PathState &s)
 {
-    q.a[slot] = make_float4(s.o.x, s.o.y, s.o.z, s.d.x);
-    q.b[slot] = make_float4(s.d.y, s.d.z, s.thr.x, s.thr.y);
-    q.c[slot] = make_float4(s.thr.z, s.rad.x, s.rad.y, s.rad.z);
-    q.rng[slot] = make_uint4(s.rng.x, s.rng.y, s.rng.z, s.rng.w);
-    q.pixel[slot] = s.pixel;
+    store_through(q.a + slot, s.o.x, s.o.y, s.o.z, s.d.x);
+    store_through(q.b + slot, s.d.y, s.d.z, s.thr.x, s.thr.y);
+    store_through(q.c + slot, s.thr.z, s.rad.x, s.rad.y, s.rad.z);
+    store_through(q.rng + slot, s.rng.x, s.rng.y, s.rng.z, s.rng.w);
+    store_through(q.pixel + slot, s.pixel);
 }
 __device__ __forceinline__ PathState load_ray(const RayQueue &q, uint32_t slot)
 {
@@ -89,11 +106,11 @@ __device__ __forceinline__ void finish_path(const FrameParams &P, const ImageVie
         float4 *pix = im.pixels + s.pixel;
         f3 prev = mk(0.0f, 0.0f, 0.0f);
         if (!P.reset_flag) { float4 q = *pix; prev = mk(q.x, q.y, q.z); }
-        *pix = accumulate_pixel(P, s.rad, prev);
+        { const float4 v = accumulate_pixel(P, s.rad, prev); store_through(pix, v.x, v.y, v.z, v.w); }
     } else {
         float4 acc = wb.sums[s.pixel];
-        wb.sums[s.pixel] = make_float4(acc.x + s.rad.x, acc.y + s.rad.y, acc.z + s.rad.z, 0.0f);
-        wb.pix_rng[s.pixel] = make_uint4(s.rng.x, s.rng.y, s.rng.z, s.rng.w);
+        store_through(wb.sums + s.pixel, acc.x + s.rad.x, acc.y + s.rad.y, acc.z + s.rad.z, 0.0f);
+        store_through(wb.pix_rng + s.pixel, s.rng.x, s.rng.y, s.rng.z, s.rng.w);
     }
     if (rng_out) rng_out[s.pixel] = make_uint4(s.rng.x, s.rng.y, s.rng.z, s.rng.w);
 }
@@ -104,12 +121,12 @@ __global__ void __launch_bounds__(256) generate_rays_kernel(FrameParams P, Image
 {
     // the ray counts of the bounces (and the word behind them) start at zero: cleared here rather than by a memset launch of their own
     // (n_counts = 0: the host has done it); nothing touches them before the first shade kernel
-    if (blockIdx.x == 0 && threadIdx.x < n_counts && threadIdx.x > 0u) wb.counts[threadIdx.x] = 0u;
+    if (blockIdx.x == 0 && threadIdx.x < n_counts && threadIdx.x > 0u) store_through(wb.counts + threadIdx.x, 0u);
     // queue order = 8x8 pixel blocks, row-major over blocks: neighbouring lanes start as neighbouring pixels
     const uint32_t idx = blockIdx.x * 256u + threadIdx.x;
     if (idx >= n0) return;
     if (idx == 0u) {
-        wb.counts[0] = n0;                               // the rest of counts[] was zeroed by the host
+        store_through(wb.counts, n0);
         if (counters) atomicAdd(&counters->paths, (unsigned long long)n0);
     }
     const uint32_t blocks_x = im.disp_w >> 3;
@@ -126,9 +143,9 @@ __global__ void __launch_bounds__(256) generate_rays_kernel(FrameParams P, Image
         s.rng.w = (uint32_t)px + (uint32_t)py + (uint32_t)P.random;
         camera_ray(P, px, py, im.width, im.height, s.rng, s.o, s.d);
         if (P.samples > 1u) {
-            wb.cam_a[s.pixel] = make_float4(s.o.x, s.o.y, s.o.z, s.d.x);
-            wb.cam_b[s.pixel] = make_float4(s.d.y, s.d.z, 0.0f, 0.0f);
-            wb.sums[s.pixel] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            store_through(wb.cam_a + s.pixel, s.o.x, s.o.y, s.o.z, s.d.x);
+            store_through(wb.cam_b + s.pixel, s.d.y, s.d.z, 0.0f, 0.0f);
+            store_through(wb.sums + s.pixel, 0.0f, 0.0f, 0.0f, 0.0f);
         }
     } else {
         float4 a = wb.cam_a[s.pixel], b = wb.cam_b[s.pixel];
@@ -138,7 +155,7 @@ __global__ void __launch_bounds__(256) generate_rays_kernel(FrameParams P, Image
     }
     s.thr = mk(1.0f, 1.0f, 1.0f); s.rad = mk(0.0f, 0.0f, 0.0f);
     store_ray(wb.q[0], idx, s);
-    if (wb.best[0]) wb.best[0][idx] = 0xFFFFFFFFFFFFFFFFull;
+    if (wb.best[0]) store_through(wb.best[0] + idx, 0xFFFFFFFFFFFFFFFFull);
 }
 
 __global__ void __launch_bounds__(256) resolve_kernel(FrameParams P, ImageView im, WaveBuffers wb)
@@ -153,7 +170,7 @@ __global__ void __launch_bounds__(256) resolve_kernel(FrameParams P, ImageView i
     f3 prev = mk(0.0f, 0.0f, 0.0f);
     if (!P.reset_flag) { float4 q = *pix; prev = mk(q.x, q.y, q.z); }
     float4 sum = wb.sums[pixel];
-    *pix = accumulate_pixel(P, mk(sum.x, sum.y, sum.z), prev);
+    { const float4 v = accumulate_pixel(P, mk(sum.x, sum.y, sum.z), prev); store_through(pix, v.x, v.y, v.z, v.w); }
 }
 
 // ---- one bounce --------------------------------------------------------------------------------------
@@ -632,7 +649,7 @@ __global__ void __launch_bounds__(256) shade_kernel(SceneView sc, FrameParams P,
         for (int w = 0; w < wave; ++w) wave_base += s_cnt[w];
         const uint32_t out_slot = wave_base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
         store_ray(qout, out_slot, s);
-        best_out[out_slot] = kNoHitKey;
+        store_through(best_out + out_slot, kNoHitKey);
     }
     __syncthreads();                                                              // s_cnt is rewritten by the next batch
     }

@@ -31,7 +31,7 @@ for name, opts in (("kernel 4, one wave", (("scan_waves", 1),)), ("kernel 4, two
             if d.any():
                 bad += 1; wrong_here = True
                 ys, xs = np.nonzero(d)
-                if bad <= 3: print("   ", name, "iteration", it, "rank", i, ":", int(d.sum()), "pixels; local (row, x) of the first:", (int(ys[0]), int(xs[0])), "global row", int(rows[ys[0]]), flush=True)
+                if bad <= 6: print("   ", name, "iteration", it, "rank", i, ":", int(d.sum()), "pixels; local rows", sorted(set(int(y) for y in ys)), "x", int(xs.min()), "..", int(xs.max()), "global row of the first", int(rows[ys[0]]), flush=True)
         seen.setdefault((cand, wrong_here), 0); seen[(cand, wrong_here)] += 1
         for c in ctxs: c.close()
     print("    (survivors counted by the scan, some image wrong) -> iterations:", seen)
