@@ -116,7 +116,7 @@ __global__ void __launch_bounds__(256) pathtrace_mega_kernel(SceneView sc, Frame
         }
         color = color + radiance;
     }
-    *pix = accumulate_pixel(P, color, prev);
+    { const float4 v = accumulate_pixel(P, color, prev); store_through(pix, v.x, v.y, v.z, v.w); }      // (rt_wavefront.hpp: read by the next frame's kernel, from whichever XCD)
     if (rng_out) rng_out[(size_t)lrow * im.width + px] = make_uint4(rng.x, rng.y, rng.z, rng.w);
     if (kCount) {
         atomicAdd(&counters->paths, (unsigned long long)P.samples);
