@@ -1,0 +1,68 @@
+"""Random scenes, random cameras, random kernel-4 options against the CPU oracle, bit for bit (image and final PCG4D states):
+triangle soups (random positions, sizes from needles to scene-sized, random windings and materials), two meshes, the demo spheres on or
+off, cube map on or off, 1..8 bounces, 1..3 frames, images whose sizes are not multiples of anything, and for the scan: one / two waves
+per SIMD, static / dynamic work distribution, cull off / camera rays / every bounce, chunks of 1..32 quads, groups of 1..64 quads.
+
+In the suite: FUZZ_CASES cases (default 60) from FUZZ_SEED (default 1).  The round-2 campaign was
+`FUZZ_CASES=1500 FUZZ_SEED=7 python -m pytest tests/test_gpu_fuzz_parity.py -m gpu -q` (+ 150 from seed 1): 0 differing cases
+(profiles/r2_fuzz_parity.txt)."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def run_cases(rt, oracle, N, seed):
+    sc = rt.scenes
+    rng = np.random.default_rng(seed)
+
+    def soup(n, mats):
+        c = rng.uniform([-18, -12, 0], [18, 6, 12], size=(n, 3))
+        size = np.where(rng.random(n) < 0.1, rng.uniform(3, 12, n), rng.uniform(0.05, 2.0, n))
+        tri = c[:, None, :] + rng.normal(size=(n, 3, 3)) * size[:, None, None]
+        if rng.random() < 0.5: tri[: n // 2, :, 2] = np.abs(tri[: n // 2, :, 2])      # something in front of the default camera
+        v = np.zeros((n, 3, 4), np.float32); v[..., :3] = tri.astype(np.float32); v[..., 3] = rng.choice(mats, size=n)[:, None]
+        return v.reshape(-1, 4)
+
+    bad = 0
+    for case in range(N):
+        n1, n2 = int(rng.integers(1, 1500)), int(rng.integers(0, 400))
+        v = np.concatenate([soup(n1, [0, 5, 7, 3]), soup(n2, [1, 2, 4])]) if n2 else soup(n1, [0, 5, 7, 3])
+        meshes = sc.make_meshes([(0, n1, 0)] + ([(n1, n2, 0)] if n2 else []))
+        spheres = sc.demo_spheres(bool(rng.integers(2))) if rng.random() < 0.7 else np.zeros((0, 8), np.float32)
+        scene = sc.Scene(spheres=spheres, materials=sc.demo_materials(), meshes=meshes, vertices=v,
+                         nodes=sc.single_leaf(len(spheres)) if len(spheres) else np.zeros((0, 12), np.float32), env=sc.sky_cubemap(16) if rng.random() < 0.7 else None)
+        W, H = int(rng.integers(40, 140)), int(rng.integers(24, 90))
+        yaw = rng.uniform(-0.3, 0.3)
+        fwd = (float(np.sin(yaw)), 0.0, float(np.cos(yaw))); right = (-float(np.cos(yaw)), 0.0, float(np.sin(yaw)))
+        p0 = sc.FrameParams(max_bounce=int(rng.integers(1, 9)), use_envmap=int(scene.env is not None), use_dof=int(rng.integers(2)),
+                            camera_position=(float(rng.uniform(-5, 5)), float(rng.uniform(-4, 2)), float(rng.uniform(-40, -20))), camera_forward=fwd, camera_right=right,
+                            camera_aperture=float(rng.choice([0.001, 0.05, 0.5])), camera_focal_length=float(rng.uniform(8, 45)))
+        opts = dict(kernel=4, scan_waves=int(rng.integers(0, 3)), scan_dynamic=int(rng.integers(0, 3)), cull=int(rng.integers(0, 3)),
+                    mf_chunk_quads=int(rng.choice([1, 2, 3, 5, 8, 16, 32])), mf_group_quads=int(rng.choice([1, 2, 4, 8, 32, 64])))
+        frames = int(rng.integers(1, 4))
+        ctx = rt.host.Context(W, H)
+        for k, val in opts.items(): ctx.set_option(k, val)
+        ctx.set_option("rng_state", 1); ctx.upload_scene(scene)
+        img_o = np.zeros((H, W, 4), np.float32); g = sc.GlibcRand(case); seeds_o = None
+        for f in range(1, frames + 1):
+            p = p0.replace(frames=f, random=g.rand())
+            ctx.render(p)
+            _, seeds_o = oracle.render(scene, p, img_o, threads=16, want_seeds=True)
+        img_g = ctx.read_image(); seeds_g = ctx.read_rng_state(); ctx.close()
+        dw, dh = W // 8 * 8, H // 8 * 8
+        neq = int((img_g.view(np.uint32) != img_o.view(np.uint32)).any(axis=2).sum()); sneq = int((seeds_g[:dh, :dw] != seeds_o[:dh, :dw]).any(axis=-1).sum()) if seeds_g.ndim == 3 else int((seeds_g[:dh, :dw] != seeds_o[:dh, :dw]).sum())
+        if neq or sneq:
+            bad += 1
+            print("case", case, ": pixels", neq, "rng states", sneq, "|", W, "x", H, "triangles", n1, "+", n2, "spheres", len(spheres), "bounces", p0.max_bounce, "frames", frames, opts, flush=True)
+    return bad
+
+
+
+def test_random_scenes_and_scan_options_match_the_oracle(rt, oracle):
+    n, seed = int(os.environ.get("FUZZ_CASES", "60")), int(os.environ.get("FUZZ_SEED", "1"))
+    bad = run_cases(rt, oracle, n, seed)
+    print("cases", n, "differing from the oracle:", bad)
+    assert bad == 0, f"{bad} of {n} random cases differ from the oracle (see the lines printed above)"
