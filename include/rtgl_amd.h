@@ -98,7 +98,9 @@ int rtgl_create_tiled(rtgl_context **out, int width, int height, int device, int
  * per device) when the image is read -- rtgl_read_image_* do it implicitly, rtgl_gather_tiles explicitly (then rtgl_device_image
  * is the assembled image on devices[0]).  Every other entry point takes the handle like a single-device one: uploads and options
  * go to all devices, counters are summed, rtgl_last_frame_ms is the slowest device.  Bit-identical to a single-device render.
- * The same ordinal may appear more than once.  rtgl_bind_device_image / rtgl_set_stream are refused on such a handle. */
+ * The same ordinal may appear more than once.  rtgl_bind_device_image / rtgl_set_stream are refused on such a handle.
+ * rtgl_render_frame hands each device's frame to a submit thread of the context's own (created here, joined in rtgl_destroy) and returns
+ * when all have submitted; the environment variable RTGL_AMD_MULTI_THREADS=0, read here, keeps submission on the caller's thread. */
 int rtgl_create_multi(rtgl_context **out, int width, int height, const int *devices, int n_devices, int strip_rows);
 int rtgl_device_count(const rtgl_context *ctx);   /* 1 for a single-device context */
 int rtgl_gather_tiles(rtgl_context *ctx);         /* enqueue the gather on devices[0]'s stream (no-op for a single-device context) */

@@ -9,6 +9,9 @@
 #include <vector>
 #include <map>
 #include <mutex>
+#include <thread>
+#include <condition_variable>
+#include <memory>
 
 #include "../../include/rtgl_amd.h"
 #include "rt_device.hpp"
@@ -149,6 +152,18 @@ __global__ void __launch_bounds__(256) image_to_u8_kernel(const float4 *__restri
 
 static thread_local std::string g_create_error;
 
+// rtgl_create_multi: one submit thread per part.  A frame is ~27 launches = ~150 us of host time per device (measured,
+// tools/diagnostics/host_enqueue.py) while a rank of 8 renders its strips of the 1080p benchmark frame in 0.68 ms: ONE thread submitting
+// to 8 devices one after the other (1.2 ms) would be the limiter, 8 threads side by side are not.
+struct PartWorker {
+    std::thread th;
+    std::mutex m;
+    std::condition_variable cv;
+    enum { kIdle, kJob, kDone, kQuit } state = kIdle;
+    int rc = 0;
+    rtgl_context *part = nullptr;
+};
+
 struct rtgl_context {
     int device = 0;
     int width = 0, height = 0;
@@ -207,6 +222,7 @@ struct rtgl_context {
     // and `parts` are the per-device tiled contexts that render the strips; every entry point fans out to them
     std::vector<rtgl_context *> parts;
     std::vector<hipEvent_t> part_done;
+    std::vector<std::unique_ptr<PartWorker>> workers;     // one per part when there is more than one (RTGL_AMD_MULTI_THREADS=0: none, the caller's thread submits)
     bool gathered = false, peer_copy = true;
 
     bool tris_dirty = false, visits_dirty = false;
@@ -319,6 +335,12 @@ extern "C" int rtgl_create(rtgl_context **out, int width, int height, int device
 extern "C" void rtgl_destroy(rtgl_context *ctx)
 {
     if (!ctx) return;
+    for (auto &w : ctx->workers) {
+        { std::lock_guard<std::mutex> lk(w->m); w->state = PartWorker::kQuit; }
+        w->cv.notify_all();
+        if (w->th.joinable()) w->th.join();
+    }
+    ctx->workers.clear();
     for (rtgl_context *part : ctx->parts) rtgl_destroy(part);
     ctx->parts.clear();
     (void)hipSetDevice(ctx->device);
@@ -396,6 +418,26 @@ extern "C" int rtgl_create_multi(rtgl_context **out, int width, int height, cons
             if (hipDeviceCanAccessPeer(&can, devices[0], devices[i]) != hipSuccess || !can) ctx->peer_copy = false;
             else { hipError_t e = hipDeviceEnablePeerAccess(devices[i], 0); if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) ctx->peer_copy = false; }
             (void)hipGetLastError();
+        }
+    }
+    const char *mt = getenv("RTGL_AMD_MULTI_THREADS");
+    if (n_devices > 1 && !(mt && atoi(mt) == 0)) {
+        for (rtgl_context *part : ctx->parts) {
+            ctx->workers.emplace_back(new PartWorker);
+            PartWorker *w = ctx->workers.back().get();
+            w->part = part;
+            w->th = std::thread([w] {
+                std::unique_lock<std::mutex> lk(w->m);
+                for (;;) {
+                    w->cv.wait(lk, [w] { return w->state == PartWorker::kJob || w->state == PartWorker::kQuit; });
+                    if (w->state == PartWorker::kQuit) return;
+                    lk.unlock();
+                    const int rc = rtgl_render_frame(w->part);      // (sets the thread's device itself: ENTER)
+                    lk.lock();
+                    w->rc = rc; w->state = PartWorker::kDone;
+                    w->cv.notify_all();
+                }
+            });
         }
     }
     *out = ctx;
@@ -967,6 +1009,18 @@ extern "C" int rtgl_set_frame_params(rtgl_context *ctx, const rtgl_frame_params 
 extern "C" int rtgl_render_frame(rtgl_context *ctx)
 {
     ENTER(ctx);
+    if (!ctx->workers.empty()) {                         // every part's frame is submitted by its own thread; this one waits for all of them
+        ctx->gathered = false;
+        for (auto &w : ctx->workers) { { std::lock_guard<std::mutex> lk(w->m); w->state = PartWorker::kJob; } w->cv.notify_all(); }
+        int first = RTGL_OK; const rtgl_context *bad = nullptr;
+        for (auto &w : ctx->workers) {
+            std::unique_lock<std::mutex> lk(w->m);
+            w->cv.wait(lk, [&w] { return w->state == PartWorker::kDone; });
+            w->state = PartWorker::kIdle;
+            if (w->rc && !first) { first = w->rc; bad = w->part; }
+        }
+        return first ? fail(ctx, first, std::string("device ") + std::to_string(bad->device) + ": " + bad->error) : RTGL_OK;
+    }
     FANOUT(ctx, rtgl_render_frame(part));
     if (!ctx->have_params) return fail(ctx, RTGL_ERR_STATE, "rtgl_set_frame_params has not been called");
     if (ctx->params.samples == 0) return fail(ctx, RTGL_ERR_INVALID, "u_samples == 0 divides by zero in the reference; refused");

@@ -198,11 +198,13 @@ def test_c2_degenerate_group_floods_the_candidate_regions(rt, monkeypatch):
     assert (img.view(np.uint32) == ref.view(np.uint32)).all()
 
 
-@pytest.mark.parametrize("devices,strip", [([0, 0], 8), ([0, 0, 0], 16)])
-def test_multi_device_context_through_the_c_abi_matches_single_context(devices, strip, rt):
+@pytest.mark.parametrize("devices,strip,threads", [([0, 0], 8, "1"), ([0, 0, 0], 16, "1"), ([0, 0, 0], 8, "0")])
+def test_multi_device_context_through_the_c_abi_matches_single_context(devices, strip, threads, rt, monkeypatch):
     """rtgl_create_multi: one handle, several tiled contexts (here all on device 0 -- also the "two contexts in one process" case
     of the per-device kernel attributes), gather by 2-D device copies into the assembler's image.  Uploads, frames, counters and the
-    image go through the ordinary entry points; the result equals the single-context render bit for bit."""
+    image go through the ordinary entry points; the result equals the single-context render bit for bit.  Every part's frame is
+    submitted by a thread of its own (RTGL_AMD_MULTI_THREADS=0, read at creation: by the caller's thread, one part after the other)."""
+    monkeypatch.setenv("RTGL_AMD_MULTI_THREADS", threads)
     sc = rt.scenes
     W, H = 328, 204                                   # 25.5 strips of 8 rows: the last strip is short
     scene = sc.scene_mesh(30, 10, env_size=32)
