@@ -83,19 +83,33 @@ def test_facade_program_matches_oracle(tmp_path, rt, oracle):
     import ctypes
     raw = open(os.path.join(d, "params.raw"), "rb").read()
     n = ctypes.sizeof(rt.host.CFrameParams)
-    used = [rt.host.CFrameParams.from_buffer_copy(raw[i * n:(i + 1) * n]) for i in range(frames)]
-    assert [(u.frames, u.reset_flag) for u in used] == [(1, 0), (2, 0), (3, 0), (4, 1), (1, 0), (2, 0)]   # renderer.cpp:98,123-127
     defaults = sc.FrameParams()
-    want = np.zeros((H, W, 4), np.float32)
-    for u in used:
-        assert u.max_bounce == 6 and u.samples == 1 and u.use_dof == 1 and u.use_envmap == 1
-        assert np.float32(u.camera_fov) == np.float32(defaults.camera_fov) and tuple(u.camera_right) == (-1.0, 0.0, 0.0)
-        p = defaults.replace(frames=u.frames, random=u.random, reset_flag=u.reset_flag, max_bounce=u.max_bounce)
-        oracle.render(scene, p, want, threads=4)
-    assert (got.view(np.uint32) == want.view(np.uint32)).all()
+
+    def expected(raw):
+        used = [rt.host.CFrameParams.from_buffer_copy(raw[i * n:(i + 1) * n]) for i in range(frames)]
+        assert [(u.frames, u.reset_flag) for u in used] == [(1, 0), (2, 0), (3, 0), (4, 1), (1, 0), (2, 0)]   # renderer.cpp:98,123-127
+        want = np.zeros((H, W, 4), np.float32)
+        for u in used:
+            assert u.max_bounce == 6 and u.samples == 1 and u.use_dof == 1 and u.use_envmap == 1
+            assert np.float32(u.camera_fov) == np.float32(defaults.camera_fov) and tuple(u.camera_right) == (-1.0, 0.0, 0.0)
+            p = defaults.replace(frames=u.frames, random=u.random, reset_flag=u.reset_flag, max_bounce=u.max_bounce)
+            oracle.render(scene, p, want, threads=4)
+        return want
+
+    assert (got.view(np.uint32) == expected(raw).view(np.uint32)).all()
     # save_to_file: render_<W>x<H>_<time>_<frames>.png, flipped, 8-bit
     pngs = [f for f in os.listdir(d) if f.startswith(f"render_{W}x{H}_") and f.endswith(".png")]
     assert len(pngs) == 1 and pngs[0].endswith(f"_{frames - reset_at}.png")
+    # the same unmodified program with the frame tiled across "three devices" (RTGL_AMD_DEVICES: rtgl_create_multi behind Renderer(w, h),
+    # one submit thread per part; the box has one GPU, so all three are device 0)
+    d2 = os.path.join(d, "tiled")
+    os.mkdir(d2)
+    for f in os.listdir(d):
+        if f.endswith((".png", ".obj")) and not f.startswith("render_"):
+            os.symlink(os.path.join(d, f), os.path.join(d2, f))
+    subprocess.check_call([exe, d2, str(W), str(H), str(frames), str(reset_at)], cwd=d2, env=dict(os.environ, RTGL_AMD_DEVICES="0,0,0"))
+    tiled = np.fromfile(os.path.join(d2, "image.raw"), np.float32).reshape(H, W, 4)
+    assert (tiled.view(np.uint32) == expected(open(os.path.join(d2, "params.raw"), "rb").read()).view(np.uint32)).all()
 
 
 REFERENCE_MAIN = "/root/reference/src/main.cpp"
