@@ -12,9 +12,11 @@
 // zeroed (item 9); set_kdtree(vec4) is accepted but only uploads the vertices (item 15: the shader would
 // read triangle nodes as sphere ranges); the ImGui panel does not exist (public setters replace it).
 #pragma once
+#include <algorithm>
 #include <array>
 #include <chrono>
 #include <cmath>
+#include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -332,7 +334,58 @@ public:
         return img;
     }
 
+
+    // ---- lossless outputs and a resumable state (the reference itself only writes the 8-bit PNG above).  Like the
+    // reference's file operations they print and return false on failure.
+    // RGBA32F as it sits in the accumulation image: width * height * 16 bytes, no header, row 0 = bottom
+    bool save_raw(const std::string &path) const
+    {
+        const std::vector<float> img = read_image();
+        return write_file(path, "", img.data(), img.size() * sizeof(float));
+    }
+    // Portable float map: "PF\n<w> <h>\n-1.0\n" (colour, little-endian), RGB float32, bottom row first -- the image's own row order
+    bool save_pfm(const std::string &path) const
+    {
+        const std::vector<float> img = read_image();
+        std::vector<float> rgb(img.size() / 4 * 3);
+        for (size_t i = 0; i < img.size() / 4; ++i) { rgb[3 * i] = img[4 * i]; rgb[3 * i + 1] = img[4 * i + 1]; rgb[3 * i + 2] = img[4 * i + 2]; }
+        const std::string head = "PF\n" + std::to_string(m_width) + " " + std::to_string(img.size() / 4 / (size_t)std::max(m_width, 1)) + "\n-1.0\n";
+        return write_file(path, head, rgb.data(), rgb.size() * sizeof(float));
+    }
+    // The progressive state: the accumulation image and the frame counters the running mean depends on (u_frames, src/renderer.cpp:98).
+    // load_state() into a Renderer of the same size continues exactly where save_state() stopped: the next frame is mixed in with
+    // weight 1 / (frames + 1) as if the process had never ended.  (u_random continues from the caller's rand() stream, which is not
+    // part of the state; scene and camera are the caller's to restore.)
+    bool save_state(const std::string &path) const
+    {
+        const std::vector<float> img = read_image();
+        StateHeader h{};
+        std::memcpy(h.magic, "RTGLST01", 8);
+        h.width = m_width; h.height = (int32_t)(img.size() / 4 / (size_t)std::max(m_width, 1)); h.frames = m_frames; h.time = m_time;
+        return write_file(path, std::string(reinterpret_cast<const char *>(&h), sizeof h), img.data(), img.size() * sizeof(float));
+    }
+    bool load_state(const std::string &path)
+    {
+        std::ifstream f(path, std::ios::binary);
+        StateHeader h{};
+        if (!f || !f.read(reinterpret_cast<char *>(&h), sizeof h) || std::memcmp(h.magic, "RTGLST01", 8) != 0) { std::cerr << "Could not read state from " << path << std::endl; return false; }
+        if (!m_ctx || h.width != m_width || h.height != rtgl_local_rows(m_ctx)) { std::cerr << "State in " << path << " is " << h.width << "x" << h.height << ", not this renderer's size" << std::endl; return false; }
+        std::vector<float> img((size_t)h.width * h.height * 4);
+        if (!f.read(reinterpret_cast<char *>(img.data()), (std::streamsize)(img.size() * sizeof(float)))) { std::cerr << "State in " << path << " is truncated" << std::endl; return false; }
+        if (rtgl_write_image_f32(m_ctx, img.data()) != RTGL_OK) { std::cerr << "rtgl: " << rtgl_last_error(m_ctx) << std::endl; return false; }
+        m_frames = h.frames; m_time = h.time; m_reset = false;
+        return true;
+    }
+
 private:
+    struct StateHeader { char magic[8]; int32_t width, height, frames; float time; };
+    static bool write_file(const std::string &path, const std::string &head, const void *data, size_t bytes)
+    {
+        std::ofstream f(path, std::ios::binary);
+        if (f) { f.write(head.data(), (std::streamsize)head.size()); f.write(static_cast<const char *>(data), (std::streamsize)bytes); }
+        if (!f) { std::cerr << "Could not write " << path << std::endl; return false; }
+        return true;
+    }
     void check(int rc) const { if (rc != RTGL_OK) std::cerr << "rtgl: " << rtgl_last_error(m_ctx) << std::endl; }
 
     rtgl_context *m_ctx = nullptr;

@@ -78,6 +78,8 @@ int main(int argc, char **argv)
     if (!have_device) return 3;
 
     renderer.set_bounces(6);
+    // resume: RTGL_DEMO_LOAD_STATE=<file> continues the accumulation a previous run saved
+    if (const char *st = std::getenv("RTGL_DEMO_LOAD_STATE")) if (!renderer.load_state(st)) return 5;
     std::vector<rtgl_frame_params> used;
     for (int f = 1; f <= frames; ++f) {
         if (f == reset_at) {                      // what pressing 'r' does in the reference (src/renderer.cpp:365-367)
@@ -95,5 +97,7 @@ int main(int argc, char **argv)
     std::vector<float> img = renderer.read_image();
     if (!dump(dir + "/image.raw", img.data(), img.size() * sizeof(float))) return 4;
     if (argc > 6) renderer.save_to_file();
+    if (const char *st = std::getenv("RTGL_DEMO_SAVE_STATE"))
+        if (!renderer.save_state(st) || !renderer.save_pfm(dir + "/image.pfm") || !renderer.save_raw(dir + "/image_rgba32f.raw")) return 6;
     return 0;
 }

@@ -85,10 +85,10 @@ def test_facade_program_matches_oracle(tmp_path, rt, oracle):
     n = ctypes.sizeof(rt.host.CFrameParams)
     defaults = sc.FrameParams()
 
-    def expected(raw):
-        used = [rt.host.CFrameParams.from_buffer_copy(raw[i * n:(i + 1) * n]) for i in range(frames)]
-        assert [(u.frames, u.reset_flag) for u in used] == [(1, 0), (2, 0), (3, 0), (4, 1), (1, 0), (2, 0)]   # renderer.cpp:98,123-127
-        want = np.zeros((H, W, 4), np.float32)
+    def expected(raw, sequence=((1, 0), (2, 0), (3, 0), (4, 1), (1, 0), (2, 0)), start=None):      # renderer.cpp:98,123-127
+        used = [rt.host.CFrameParams.from_buffer_copy(raw[i * n:(i + 1) * n]) for i in range(len(sequence))]
+        assert [(u.frames, u.reset_flag) for u in used] == list(sequence)
+        want = np.zeros((H, W, 4), np.float32) if start is None else start.copy()
         for u in used:
             assert u.max_bounce == 6 and u.samples == 1 and u.use_dof == 1 and u.use_envmap == 1
             assert np.float32(u.camera_fov) == np.float32(defaults.camera_fov) and tuple(u.camera_right) == (-1.0, 0.0, 0.0)
@@ -110,6 +110,33 @@ def test_facade_program_matches_oracle(tmp_path, rt, oracle):
     subprocess.check_call([exe, d2, str(W), str(H), str(frames), str(reset_at)], cwd=d2, env=dict(os.environ, RTGL_AMD_DEVICES="0,0,0"))
     tiled = np.fromfile(os.path.join(d2, "image.raw"), np.float32).reshape(H, W, 4)
     assert (tiled.view(np.uint32) == expected(open(os.path.join(d2, "params.raw"), "rb").read()).view(np.uint32)).all()
+    # lossless outputs and the resumable state.  Run A renders three frames and saves; run B, a new process, loads the state
+    # and renders three more: its uniforms continue the frame count (u_frames 4, 5, 6) and its image is the oracle's running mean over
+    # A's image -- exactly what an uninterrupted run accumulates
+    def fresh(name):
+        dn = os.path.join(d, name)
+        os.mkdir(dn)
+        for f in os.listdir(d):
+            if f.endswith((".png", ".obj")) and not f.startswith("render_"):
+                os.symlink(os.path.join(d, f), os.path.join(dn, f))
+        return dn
+    da, db = fresh("run_a"), fresh("run_b")
+    state = os.path.join(d, "state.bin")
+    subprocess.check_call([exe, da, str(W), str(H), "3", "0"], cwd=da, env=dict(os.environ, RTGL_DEMO_SAVE_STATE=state))
+    img_a = np.fromfile(os.path.join(da, "image.raw"), np.float32).reshape(H, W, 4)
+    assert (img_a.view(np.uint32) == expected(open(os.path.join(da, "params.raw"), "rb").read(), ((1, 0), (2, 0), (3, 0))).view(np.uint32)).all()
+    blob = open(state, "rb").read()
+    assert blob[:8] == b"RTGLST01" and struct.unpack("<iii", blob[8:20]) == (W, H, 3) and len(blob) == 24 + W * H * 16
+    assert blob[24:] == img_a.tobytes() == open(os.path.join(da, "image_rgba32f.raw"), "rb").read()
+    pfm = open(os.path.join(da, "image.pfm"), "rb").read()
+    head = f"PF\n{W} {H}\n-1.0\n".encode()
+    assert pfm.startswith(head) and pfm[len(head):] == np.ascontiguousarray(img_a[:, :, :3]).tobytes()
+    subprocess.check_call([exe, db, str(W), str(H), "3", "0"], cwd=db, env=dict(os.environ, RTGL_DEMO_LOAD_STATE=state))
+    img_b = np.fromfile(os.path.join(db, "image.raw"), np.float32).reshape(H, W, 4)
+    want_b = expected(open(os.path.join(db, "params.raw"), "rb").read(), ((4, 0), (5, 0), (6, 0)), start=img_a)
+    assert (img_b.view(np.uint32) == want_b.view(np.uint32)).all()
+    # a state of another size is refused (printed, like the reference's file errors) and the run stops
+    assert subprocess.call([exe, fresh("run_c"), str(W + 8), str(H), "1", "0"], cwd=d, env=dict(os.environ, RTGL_DEMO_LOAD_STATE=state)) == 5
 
 
 REFERENCE_MAIN = "/root/reference/src/main.cpp"
