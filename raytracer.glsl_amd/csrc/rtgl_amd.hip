@@ -421,7 +421,7 @@ extern "C" int rtgl_create_multi(rtgl_context **out, int width, int height, cons
         }
     }
     const char *mt = getenv("RTGL_AMD_MULTI_THREADS");
-    if (n_devices > 1 && !(mt && atoi(mt) == 0)) {
+    if (n_devices > 1 && !(mt && atoi(mt) == 0)) try {
         for (rtgl_context *part : ctx->parts) {
             ctx->workers.emplace_back(new PartWorker);
             PartWorker *w = ctx->workers.back().get();
@@ -439,6 +439,13 @@ extern "C" int rtgl_create_multi(rtgl_context **out, int width, int height, cons
                 }
             });
         }
+    } catch (const std::exception &) {                   // no threads to be had: the caller's thread submits, as with RTGL_AMD_MULTI_THREADS=0
+        for (auto &w : ctx->workers) {
+            { std::lock_guard<std::mutex> lk(w->m); w->state = PartWorker::kQuit; }
+            w->cv.notify_all();
+            if (w->th.joinable()) w->th.join();
+        }
+        ctx->workers.clear();
     }
     *out = ctx;
     return RTGL_OK;
