@@ -56,7 +56,13 @@ struct WaveBuffers {
     uint32_t *sched;              // kernel 4: per scan launch (bounce) and chunk the next unclaimed item; zeroed with the ray counts at frame start
     uint32_t sched_stride;        //   entries per bounce
     uint32_t *cand_peak;          // max over the frame's scan waves of the pairs a wave wanted to append (host: sizes the regions)
+    float4 *batch_rad;            // frame batching (option "frame_batch"): the paths of B consecutive frames travel through ONE set of launches;
+    uint32_t batch_px;            //   a finished path leaves its radiance in batch_rad[frame slot * batch_px + pixel] (the slot rides in the top
+                                  //   four bits of the path's pixel word), resolve_batch_kernel folds the slots into the image in frame order
 };
+constexpr uint32_t kBatchMax = 8u;            // frames per batch
+constexpr uint32_t kBatchPixelMask = 0x0FFFFFFFu;
+struct BatchInfo { uint32_t n; int32_t frames[kBatchMax]; int32_t reset[kBatchMax]; };
 
 struct PathState { f3 o, d, thr, rad; Rng rng; uint32_t pixel; };
 
@@ -102,6 +108,10 @@ __device__ __forceinline__ PathState load_ray(const RayQueue &q, uint32_t slot)
 __device__ __forceinline__ void finish_path(const FrameParams &P, const ImageView &im, const WaveBuffers &wb,
                                             const PathState &s, uint4 *rng_out)
 {
+    if (wb.batch_rad) {                  // batched frames: the image is updated by resolve_batch_kernel, in frame order
+        store_through(wb.batch_rad + ((size_t)(s.pixel >> 28) * wb.batch_px + (s.pixel & kBatchPixelMask)), s.rad.x, s.rad.y, s.rad.z, 0.0f);
+        return;
+    }
     if (P.samples == 1u) {
         float4 *pix = im.pixels + s.pixel;
         f3 prev = mk(0.0f, 0.0f, 0.0f);
@@ -117,7 +127,10 @@ __device__ __forceinline__ void finish_path(const FrameParams &P, const ImageVie
 
 // ---- queue 0 ---------------------------------------------------------------------------------------
 // sample 0: camera rays from scratch.  sample > 0: same camera ray, RNG continued (:556-559).
-__global__ void __launch_bounds__(256) generate_rays_kernel(FrameParams P, ImageView im, WaveBuffers wb, uint32_t sample, uint32_t n0, Counters *counters, uint32_t n_counts)
+// Frame batching: the launch of frame f of a batch writes slots [slot_off, slot_off + n0) with pixel_tag = f << 28; only the first stores
+// the batch's ray count (count0 = rays of all its frames; 0: leave the count alone).  A single frame: slot_off = pixel_tag = 0, count0 = n0.
+__global__ void __launch_bounds__(256) generate_rays_kernel(FrameParams P, ImageView im, WaveBuffers wb, uint32_t sample, uint32_t n0, Counters *counters, uint32_t n_counts,
+                                                            uint32_t slot_off, uint32_t pixel_tag, uint32_t count0)
 {
     // the ray counts of the bounces (and the word behind them) start at zero: cleared here rather than by a memset launch of their own
     // (n_counts = 0: the host has done it); nothing touches them before the first shade kernel
@@ -126,7 +139,7 @@ __global__ void __launch_bounds__(256) generate_rays_kernel(FrameParams P, Image
     const uint32_t idx = blockIdx.x * 256u + threadIdx.x;
     if (idx >= n0) return;
     if (idx == 0u) {
-        store_through(wb.counts, n0);
+        if (count0) store_through(wb.counts, count0);
         if (counters) atomicAdd(&counters->paths, (unsigned long long)n0);
     }
     const uint32_t blocks_x = im.disp_w >> 3;
@@ -154,8 +167,32 @@ __global__ void __launch_bounds__(256) generate_rays_kernel(FrameParams P, Image
         s.rng.x = g.x; s.rng.y = g.y; s.rng.z = g.z; s.rng.w = g.w;
     }
     s.thr = mk(1.0f, 1.0f, 1.0f); s.rad = mk(0.0f, 0.0f, 0.0f);
-    store_ray(wb.q[0], idx, s);
-    if (wb.best[0]) store_through(wb.best[0] + idx, 0xFFFFFFFFFFFFFFFFull);
+    s.pixel |= pixel_tag;
+    store_ray(wb.q[0], slot_off + idx, s);
+    if (wb.best[0]) store_through(wb.best[0] + (slot_off + idx), 0xFFFFFFFFFFFFFFFFull);
+}
+
+// Frame batching: the running mean of main() (:561-568) applied once per frame of the batch, oldest first, from the radiance each
+// frame's path left in its slot -- the same operations in the same order as B separate frames.
+__global__ void __launch_bounds__(256) resolve_batch_kernel(ImageView im, WaveBuffers wb, BatchInfo bi)
+{
+    const uint32_t idx = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t blocks_x = im.disp_w >> 3;
+    const uint32_t blk = idx >> 6, in = idx & 63u;
+    const int px = (int)((blk % blocks_x) * 8u + (in & 7u)), lrow = (int)((blk / blocks_x) * 8u + (in >> 3));
+    if (lrow >= im.local_rows || local_to_global_row(im, lrow) >= im.disp_h) return;
+    const uint32_t pixel = (uint32_t)lrow * (uint32_t)im.width + (uint32_t)px;
+    float4 *pix = im.pixels + pixel;
+    float4 cur = *pix;
+    FrameParams P{};
+    P.samples = 1u;
+    for (uint32_t f = 0; f < bi.n; ++f) {
+        const float4 r = wb.batch_rad[(size_t)f * wb.batch_px + pixel];
+        P.frames = bi.frames[f];
+        const f3 prev = bi.reset[f] ? mk(0.0f, 0.0f, 0.0f) : mk(cur.x, cur.y, cur.z);
+        cur = accumulate_pixel(P, mk(r.x, r.y, r.z), prev);
+    }
+    store_through(pix, cur.x, cur.y, cur.z, cur.w);
 }
 
 __global__ void __launch_bounds__(256) resolve_kernel(FrameParams P, ImageView im, WaveBuffers wb)

@@ -225,10 +225,15 @@ struct rtgl_context {
     std::vector<std::unique_ptr<PartWorker>> workers;     // one per part when there is more than one (RTGL_AMD_MULTI_THREADS=0: none, the caller's thread submits)
     bool gathered = false, peer_copy = true;
 
+    // frame batching (option "frame_batch" = B > 1): rtgl_render_frame only records the frame's uniforms until B frames are waiting (or
+    // anything else is asked of the context); the B frames then travel through one set of launches (render_batch)
+    std::vector<FrameParams> pending;
+    float4 *d_batch_rad = nullptr; size_t batch_capacity = 0;
+    uint32_t last_batch_frames = 1;
     bool tris_dirty = false, visits_dirty = false;
     FrameParams params{};
     bool have_params = false;
-    int opt_kernel = RTGL_KERNEL_WAVEFRONT_MFMA_SOLO, opt_rng_state = 0, opt_counters = 0, opt_kernel_timing = 0, opt_wf_rays = 4, opt_wf_mode = kLds, opt_wf_chunk = 256, opt_wf_early = 0, opt_wf_packed = 0, opt_mf_chunk_quads = 32, opt_mf_group_quads = 32, opt_cull = 1, opt_scan_waves = 0, opt_scan_dynamic = 0, opt_debug_skip_exact = 0;
+    int opt_kernel = RTGL_KERNEL_WAVEFRONT_MFMA_SOLO, opt_rng_state = 0, opt_counters = 0, opt_kernel_timing = 0, opt_wf_rays = 4, opt_wf_mode = kLds, opt_wf_chunk = 256, opt_wf_early = 0, opt_wf_packed = 0, opt_mf_chunk_quads = 32, opt_mf_group_quads = 32, opt_cull = 1, opt_scan_waves = 0, opt_scan_dynamic = 0, opt_debug_skip_exact = 0, opt_frame_batch = 1;
 };
 
 static int fail(rtgl_context *ctx, int code, const std::string &msg)
@@ -322,6 +327,7 @@ extern "C" int rtgl_create_tiled(rtgl_context **out, int width, int height, int 
     // operational override of the default scan without touching the caller: RTGL_AMD_KERNEL=0, 1, 2 or 4 (rtgl_set_option still wins)
     if (const char *k = getenv("RTGL_AMD_KERNEL")) { const int v = atoi(k); if (v >= RTGL_KERNEL_MEGA && v <= RTGL_KERNEL_WAVEFRONT_MFMA_SOLO && v != RTGL_KERNEL_REMOVED_3) { ctx->opt_kernel = v; ctx->kernel_explicit = true; } }
     if (const char *k = getenv("RTGL_AMD_SCAN_WAVES")) { const int v = atoi(k); if (v >= 0 && v <= 2) ctx->opt_scan_waves = v; }   // A/B of the scan's occupancy
+    if (const char *k = getenv("RTGL_AMD_FRAME_BATCH")) { const int v = atoi(k); if (v >= 1 && v <= (int)kBatchMax) ctx->opt_frame_batch = v; }
     if (const char *k = getenv("RTGL_AMD_SCAN_DYNAMIC")) { const int v = atoi(k); if (v >= 0 && v <= 2) ctx->opt_scan_dynamic = v; }   // ... and of its work distribution
     *out = ctx;
     return RTGL_OK;
@@ -371,7 +377,7 @@ extern "C" void rtgl_destroy(rtgl_context *ctx)
 #endif
     void *ptrs[] = { ctx->d_spheres, ctx->d_materials, ctx->d_vertices, ctx->d_sphere_visits, ctx->d_edges, ctx->d_planes,
                      ctx->d_env, ctx->d_image_own, ctx->d_rng, ctx->d_counters, ctx->d_u8, ctx->d_group_bounds, ctx->d_wave, ctx->d_counts, ctx->d_mf_groups, ctx->d_mf_A, ctx->d_mf_order,
-                     ctx->d_dbg_log, ctx->d_cand, ctx->d_mf_cull, ctx->d_keep, ctx->d_items, ctx->d_sched, ctx->d_edges_s, ctx->d_planes_s };
+                     ctx->d_dbg_log, ctx->d_cand, ctx->d_mf_cull, ctx->d_keep, ctx->d_items, ctx->d_sched, ctx->d_edges_s, ctx->d_planes_s, ctx->d_batch_rad };
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (hipEvent_t e : ctx->kev) (void)hipEventDestroy(e);
     if (ctx->h_counts) (void)hipHostFree(ctx->h_counts);
@@ -384,7 +390,10 @@ extern "C" void rtgl_destroy(rtgl_context *ctx)
 
 extern "C" const char *rtgl_last_error(const rtgl_context *ctx) { return ctx ? ctx->error.c_str() : g_create_error.c_str(); }
 
-#define ENTER(ctx) do { if (!(ctx)) return RTGL_ERR_INVALID; HIPCHK(ctx, hipSetDevice((ctx)->device)); } while (0)
+static int flush_pending(rtgl_context *ctx);
+#define ENTER_NOFLUSH(ctx) do { if (!(ctx)) return RTGL_ERR_INVALID; HIPCHK(ctx, hipSetDevice((ctx)->device)); } while (0)
+// every entry point but rtgl_render_frame / rtgl_set_frame_params first submits the frames a batching context is still holding back
+#define ENTER(ctx) do { ENTER_NOFLUSH(ctx); if (!(ctx)->pending.empty()) { const int rcf_ = flush_pending(ctx); if (rcf_) return rcf_; } } while (0)
 // multi-device context: run `call` on every part, report the first failure through the assembler
 #define FANOUT(ctx, call) do { if (!(ctx)->parts.empty()) { (ctx)->gathered = false; \
     for (rtgl_context *part : (ctx)->parts) { const int rc_ = (call); if (rc_) return fail(ctx, rc_, std::string("device ") + std::to_string(part->device) + ": " + part->error); } \
@@ -462,6 +471,7 @@ static int multi_gather(rtgl_context *ctx)
     std::vector<float> host;
     for (int i = 0; i < world; ++i) {
         rtgl_context *part = ctx->parts[i];
+        if (!part->pending.empty()) { HIPCHK(ctx, hipSetDevice(part->device)); const int rc = flush_pending(part); if (rc) return fail(ctx, rc, part->error); }
         const int full = part->local_rows / sr, tail_rows = part->local_rows - full * sr;       // only the owner of the last strip has a short one
         uint8_t *dst = reinterpret_cast<uint8_t *>(ctx->d_image) + (size_t)i * strip_bytes;
         const uint8_t *src = reinterpret_cast<const uint8_t *>(part->d_image);
@@ -927,9 +937,13 @@ static int launch_intersect_solo(rtgl_context *ctx, const SceneView &sc, uint32_
     return RTGL_OK;
 }
 
-static int launch_wavefront(rtgl_context *ctx, const SceneView &sc, const FrameParams &P, const ImageView &im, uint32_t n0, uint4 *rng_out)
+// frames.size() > 1: a batch -- every frame's camera rays are generated into its own stretch of queue 0 (n0_frame slots), everything
+// behind that sees ONE frame of n0 = B x n0_frame rays, and resolve_batch_kernel applies the frames' results to the image in order
+static int launch_wavefront(rtgl_context *ctx, const SceneView &sc, const std::vector<FrameParams> &frames, const ImageView &im, uint32_t n0_frame, uint4 *rng_out)
 {
-    const dim3 gen_grid((n0 + 255) / 256);
+    const FrameParams &P = frames[0];
+    const uint32_t B = (uint32_t)frames.size(), n0 = n0_frame * B;
+    const dim3 gen_grid((n0_frame + 255) / 256);
     // pick up the ray counts of the most recent finished frame (never blocks)
     if (ctx->counts_pending && hipEventQuery(ctx->counts_ev) == hipSuccess) {
         ctx->counts_pending = false;
@@ -944,8 +958,9 @@ static int launch_wavefront(rtgl_context *ctx, const SceneView &sc, const FrameP
         if (!n_counts) HIPCHK(ctx, hipMemsetAsync(ctx->d_counts, 0, counts_bytes(ctx->counts_capacity), ctx->stream));
         if (ctx->opt_kernel == RTGL_KERNEL_WAVEFRONT_MFMA_SOLO && ctx->d_sched && solo_dynamic(ctx))       // the scan launches' work counters (rt_scan.hpp)
             HIPCHK(ctx, hipMemsetAsync(ctx->d_sched, 0, (size_t)(P.max_bounce + 2) * ctx->wb.sched_stride * sizeof(uint32_t), ctx->stream));
-        hipLaunchKernelGGL(generate_rays_kernel, gen_grid, dim3(256), 0, ctx->stream, P, im, ctx->wb, s, n0,
-                           ctx->opt_counters ? ctx->d_counters : (Counters *)nullptr, n_counts);
+        for (uint32_t f = 0; f < B; ++f)
+            hipLaunchKernelGGL(generate_rays_kernel, gen_grid, dim3(256), 0, ctx->stream, frames[f], im, ctx->wb, s, n0_frame,
+                               ctx->opt_counters ? ctx->d_counters : (Counters *)nullptr, f == 0 ? n_counts : 0u, f * n0_frame, B > 1 ? f << 28 : 0u, f == 0 ? n0 : 0u);
         for (uint32_t b = 0; b < P.max_bounce; ++b) {
             const int key = ctx->opt_wf_mode * 10 + ctx->opt_wf_rays;
             if (ctx->opt_kernel == RTGL_KERNEL_WAVEFRONT_SPLIT || ctx->opt_kernel == RTGL_KERNEL_WAVEFRONT_MFMA_SOLO) {
@@ -993,6 +1008,13 @@ static int launch_wavefront(rtgl_context *ctx, const SceneView &sc, const FrameP
         hipLaunchKernelGGL(resolve_kernel, gen_grid, dim3(256), 0, ctx->stream, P, im, ctx->wb);
         HIPCHK(ctx, hipGetLastError());
     }
+    if (B > 1) {
+        BatchInfo bi{};
+        bi.n = B;
+        for (uint32_t f = 0; f < B; ++f) { bi.frames[f] = frames[f].frames; bi.reset[f] = frames[f].reset_flag; }
+        hipLaunchKernelGGL(resolve_batch_kernel, gen_grid, dim3(256), 0, ctx->stream, im, ctx->wb, bi);
+        HIPCHK(ctx, hipGetLastError());
+    }
     if (!ctx->counts_pending) {      // feed the next frames' grid sizes; skipped while an earlier copy is in flight
         ctx->counts_len = P.max_bounce + 1; ctx->counts_n0 = n0;
         HIPCHK(ctx, hipMemcpyAsync(ctx->h_counts, ctx->d_counts, counts_bytes(ctx->counts_capacity), hipMemcpyDeviceToHost, ctx->stream));
@@ -1004,7 +1026,7 @@ static int launch_wavefront(rtgl_context *ctx, const SceneView &sc, const FrameP
 
 extern "C" int rtgl_set_frame_params(rtgl_context *ctx, const rtgl_frame_params *p)
 {
-    ENTER(ctx);
+    ENTER_NOFLUSH(ctx);
     FANOUT(ctx, rtgl_set_frame_params(part, p));
     if (!p) return fail(ctx, RTGL_ERR_INVALID, "params is NULL");
     static_assert(sizeof(FrameParams) == sizeof(rtgl_frame_params), "FrameParams mirrors rtgl_frame_params");
@@ -1013,9 +1035,25 @@ extern "C" int rtgl_set_frame_params(rtgl_context *ctx, const rtgl_frame_params 
     return RTGL_OK;
 }
 
+static int render_batch(rtgl_context *ctx, const std::vector<FrameParams> &batch);
+
+// what the frames of a batch must share: everything the kernels behind ray generation read from the uniforms
+static bool batch_compatible(const FrameParams &a, const FrameParams &b)
+{
+    return a.samples == b.samples && a.max_bounce == b.max_bounce && a.use_envmap == b.use_envmap && memcmp(a.background, b.background, sizeof a.background) == 0;
+}
+
+static int flush_pending(rtgl_context *ctx)
+{
+    if (ctx->pending.empty()) return RTGL_OK;
+    std::vector<FrameParams> batch;
+    batch.swap(ctx->pending);
+    return render_batch(ctx, batch);
+}
+
 extern "C" int rtgl_render_frame(rtgl_context *ctx)
 {
-    ENTER(ctx);
+    ENTER_NOFLUSH(ctx);
     if (!ctx->workers.empty()) {                         // every part's frame is submitted by its own thread; this one waits for all of them
         ctx->gathered = false;
         for (auto &w : ctx->workers) { { std::lock_guard<std::mutex> lk(w->m); w->state = PartWorker::kJob; } w->cv.notify_all(); }
@@ -1031,6 +1069,22 @@ extern "C" int rtgl_render_frame(rtgl_context *ctx)
     FANOUT(ctx, rtgl_render_frame(part));
     if (!ctx->have_params) return fail(ctx, RTGL_ERR_STATE, "rtgl_set_frame_params has not been called");
     if (ctx->params.samples == 0) return fail(ctx, RTGL_ERR_INVALID, "u_samples == 0 divides by zero in the reference; refused");
+    // frame batching: hold the frame back until the batch is full.  Only what the batched pipeline covers: one sample per frame, the
+    // per-bounce pipeline (a scene with triangles), no per-frame read-outs (counters, RNG states)
+    const bool batchable = ctx->opt_frame_batch > 1 && ctx->params.samples == 1 && ctx->params.max_bounce > 0 && !ctx->opt_counters && !ctx->opt_rng_state
+                           && !ctx->opt_kernel_timing && (ctx->n_tri_visits > 0 || ctx->tris_dirty || ctx->kernel_explicit) && ctx->opt_kernel != RTGL_KERNEL_MEGA;
+    if (!ctx->pending.empty() && (!batchable || !batch_compatible(ctx->pending.front(), ctx->params))) { const int rc = flush_pending(ctx); if (rc) return rc; }
+    if (batchable) {
+        ctx->pending.push_back(ctx->params);
+        return (int)ctx->pending.size() >= ctx->opt_frame_batch ? flush_pending(ctx) : RTGL_OK;
+    }
+    return render_batch(ctx, std::vector<FrameParams>(1, ctx->params));
+}
+
+// one frame, or the frames of a batch in one set of launches
+static int render_batch(rtgl_context *ctx, const std::vector<FrameParams> &batch)
+{
+    const uint32_t B = (uint32_t)batch.size();
     if (ctx->visits_dirty) { int rc = rebuild_sphere_visits(ctx); if (rc) return rc; }
     if (ctx->tris_dirty) { int rc = rebuild_triangles(ctx); if (rc) return rc; }
     if (ctx->opt_rng_state && !ctx->d_rng)
@@ -1042,8 +1096,9 @@ extern "C" int rtgl_render_frame(rtgl_context *ctx)
     sc.materials = ctx->d_materials; sc.n_materials = ctx->n_materials;
     sc.tri_edges = ctx->d_edges; sc.tri_planes = ctx->d_planes; sc.n_tri_visits = ctx->n_tri_visits;
     sc.env = ctx->d_env; sc.env_w = ctx->env_w; sc.env_h = ctx->env_h; sc.env_c = ctx->env_c; sc.env_faces = ctx->env_faces;
-    FrameParams P = ctx->params;
-    if (!ctx->d_env) P.use_envmap = 0;   // src/renderer.cpp:104-110: no cube map => u_use_envmap = false
+    std::vector<FrameParams> frames(batch);
+    for (FrameParams &f : frames) if (!ctx->d_env) f.use_envmap = 0;   // src/renderer.cpp:104-110: no cube map => u_use_envmap = false
+    const FrameParams &P = frames[0];
     ImageView im{};
     im.pixels = ctx->d_image; im.width = ctx->width; im.height = ctx->height;
     im.disp_w = ctx->width / 8 * 8; im.disp_h = ctx->height / 8 * 8;
@@ -1053,14 +1108,31 @@ extern "C" int rtgl_render_frame(rtgl_context *ctx)
     // rows of the dispatch footprint held locally: a prefix of the local rows (strips are 8-row aligned)
     int local_disp_rows = 0;
     for (int lr = 0; lr < ctx->local_rows; ++lr) if (rtgl_local_row_to_global(ctx, lr) < im.disp_h) local_disp_rows = lr + 1;
-    const uint32_t n0 = (uint32_t)im.disp_w * (uint32_t)local_disp_rows;
+    const uint32_t n0_frame = (uint32_t)im.disp_w * (uint32_t)local_disp_rows;
+    if ((uint64_t)n0_frame * B > 0xFFFFFFF0ull || (size_t)std::max(ctx->local_rows, 1) * ctx->width > (size_t)kBatchPixelMask) return fail(ctx, RTGL_ERR_INVALID, "frame_batch: the batch does not fit 32-bit ray slots");
+    const uint32_t n0 = n0_frame * B;            // rays entering bounce 0: all frames of the batch
     uint4 *rng_out = ctx->opt_rng_state ? ctx->d_rng : nullptr;
     // a scene without triangles has no scan to split off: one megakernel launch per frame beats the per-bounce pipeline
     // (C1, 256x256 spheres: 1460 vs 1025 Mpaths/s) unless the caller asked for a specific variant
     const int kernel = (ctx->n_tri_visits == 0 && !ctx->kernel_explicit) ? (int)RTGL_KERNEL_MEGA : ctx->opt_kernel;
     const bool use_wavefront = kernel != RTGL_KERNEL_MEGA && P.max_bounce > 0;
     ctx->kernel_in_use = use_wavefront ? kernel : (int)RTGL_KERNEL_MEGA;
+    if (B > 1 && !(use_wavefront && n0 > 0)) {          // (nothing to batch: a scene that lost its triangles meanwhile, an empty tile) one frame at a time
+        for (const FrameParams &f : batch) { const int rc = render_batch(ctx, std::vector<FrameParams>(1, f)); if (rc) return rc; }
+        return RTGL_OK;
+    }
     if (use_wavefront && n0 > 0) { int rc = ensure_wave_buffers(ctx, n0, P.max_bounce, P.samples > 1); if (rc) return rc; }
+    ctx->wb.batch_rad = nullptr; ctx->wb.batch_px = 0;
+    if (B > 1) {
+        const size_t local_px = (size_t)std::max(ctx->local_rows, 1) * ctx->width, need = local_px * B;
+        if (ctx->batch_capacity < need) {
+            if (ctx->d_batch_rad) { HIPCHK(ctx, hipFree(ctx->d_batch_rad)); ctx->d_batch_rad = nullptr; }
+            HIPCHK(ctx, hipMalloc((void **)&ctx->d_batch_rad, need * sizeof(float4)));
+            ctx->batch_capacity = need;
+        }
+        ctx->wb.batch_rad = ctx->d_batch_rad; ctx->wb.batch_px = (uint32_t)local_px;
+    }
+    ctx->last_batch_frames = B;
     HIPCHK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
     // option kernel_timing = N: every N-th frame since the last reset carries the event pairs (each pair costs ~3 us of gap)
     ctx->timing_this_frame = ctx->opt_kernel_timing > 0 && (ctx->timing_frame_counter++ % (uint32_t)ctx->opt_kernel_timing) == 0u;
@@ -1079,7 +1151,7 @@ extern "C" int rtgl_render_frame(rtgl_context *ctx)
         kev_mark(ctx);
         HIPCHK(ctx, hipGetLastError());
     } else if (n0 > 0) {
-        int rc = launch_wavefront(ctx, sc, P, im, n0, rng_out);
+        int rc = launch_wavefront(ctx, sc, frames, im, n0_frame, rng_out);
         if (rc) return rc;
     }
     HIPCHK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
@@ -1109,6 +1181,7 @@ extern "C" int rtgl_last_frame_ms(rtgl_context *ctx, float *ms)
     if (!ms || !ctx->timed) return fail(ctx, RTGL_ERR_STATE, "no frame has been rendered");
     HIPCHK(ctx, hipEventSynchronize(ctx->ev1));
     HIPCHK(ctx, hipEventElapsedTime(ms, ctx->ev0, ctx->ev1));
+    *ms /= (float)std::max(ctx->last_batch_frames, 1u);          // a batch of frames was timed as one
     return RTGL_OK;
 }
 
@@ -1225,7 +1298,12 @@ extern "C" int rtgl_local_row_to_global(const rtgl_context *ctx, int lr)
     return (ls * ctx->world + ctx->rank) * ctx->strip_rows + within;
 }
 
-extern "C" void *rtgl_device_image(rtgl_context *ctx) { return ctx ? (void *)ctx->d_image : nullptr; }
+extern "C" void *rtgl_device_image(rtgl_context *ctx)
+{
+    if (!ctx) return nullptr;
+    if (!ctx->pending.empty() && hipSetDevice(ctx->device) == hipSuccess) (void)flush_pending(ctx);     // frames a batching context still holds back
+    return (void *)ctx->d_image;
+}
 
 extern "C" int rtgl_bind_device_image(rtgl_context *ctx, void *dptr)
 {
@@ -1316,6 +1394,9 @@ extern "C" int rtgl_set_option(rtgl_context *ctx, const char *key, int value)
     } else if (!strcmp(key, "scan_dynamic")) {
         if (value < 0 || value > 2) return fail(ctx, RTGL_ERR_INVALID, "scan_dynamic must be 0 (chosen by the mesh), 1 (static) or 2 (dynamic)");
         ctx->opt_scan_dynamic = value;
+    } else if (!strcmp(key, "frame_batch")) {
+        if (value < 1 || value > (int)kBatchMax) return fail(ctx, RTGL_ERR_INVALID, "frame_batch (consecutive frames traced in one set of launches) must be 1..8");
+        ctx->opt_frame_batch = value;
     } else if (!strcmp(key, "cull")) {
         if (value < 0 || value > 2) return fail(ctx, RTGL_ERR_INVALID, "cull must be 0 (off), 1 (camera rays) or 2 (every bounce)");
         ctx->opt_cull = value;
@@ -1359,6 +1440,7 @@ extern "C" int rtgl_get_option(rtgl_context *ctx, const char *key, int *value)
     else if (!strcmp(key, "cull")) *value = ctx->opt_cull;
     else if (!strcmp(key, "scan_waves")) *value = ctx->opt_scan_waves;
     else if (!strcmp(key, "scan_dynamic")) *value = ctx->opt_scan_dynamic;
+    else if (!strcmp(key, "frame_batch")) *value = ctx->opt_frame_batch;
     else if (!strcmp(key, "rng_state")) *value = ctx->opt_rng_state;
     else if (!strcmp(key, "counters")) *value = ctx->opt_counters;
     else if (!strcmp(key, "kernel_timing")) *value = ctx->opt_kernel_timing;
@@ -1369,6 +1451,7 @@ extern "C" int rtgl_get_option(rtgl_context *ctx, const char *key, int *value)
         b += ((size_t)ctx->cand_regions * ctx->cand_region_pairs) * 8 + (size_t)ctx->cand_regions * 4;
         b += (size_t)ctx->n_tri_visits * (sizeof(TriEdges) + sizeof(TriPlane) + 4 + 112) + (size_t)ctx->n_vec4 * 16 + (size_t)ctx->env_faces * ctx->env_w * ctx->env_h * ctx->env_c;
         if (ctx->d_rng) b += (size_t)std::max(ctx->local_rows, 1) * ctx->width * 16;
+        b += ctx->batch_capacity * 16;
         *value = (int)((b + (1u << 20) - 1) >> 20);
     }
     else return fail(ctx, RTGL_ERR_INVALID, std::string("unknown option ") + key);

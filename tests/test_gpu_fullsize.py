@@ -231,6 +231,49 @@ def test_multi_device_context_through_the_c_abi_matches_single_context(devices, 
     assert cnt["paths"] == cnt_ref["paths"] and cnt["segments"] == cnt_ref["segments"]
 
 
+@pytest.mark.parametrize("batch,kw,options", [
+    (4, {}, ()), (3, {"rank": 1, "world": 3, "strip_rows": 8}, ()), (2, {"devices": [0, 0], "strip_rows": 8}, ()), (8, {}, (("kernel", 2),)),
+    (4, {}, (("scan_dynamic", 2), ("cull", 2))), (2, {}, (("kernel", 1),))])
+def test_batched_frames_equal_frames_rendered_one_by_one(batch, kw, options, rt):
+    """Option "frame_batch" = B: rtgl_render_frame holds frames back until B are waiting, then traces them in ONE set of launches (queues B times as
+    long, the frame's slot in the top bits of the pixel word, radiance parked per slot, the running mean applied in frame order by
+    resolve_batch_kernel).  The image after every read-back equals the frame-by-frame render bit for bit: 11 frames with a camera change (allowed
+    inside a batch), a reset frame in the middle (honoured by the resolve), a change of the bounce limit (closes the batch), a read-back in the
+    middle (submits a partial batch) and a last partial batch."""
+    sc = rt.scenes
+    W, H = 328, 204
+    scene = sc.scene_mesh(30, 10, env_size=32)
+    base = sc.params_c2()
+    g = sc.GlibcRand(0)
+    plist = []
+    for f in range(1, 12):
+        p = base.replace(frames=f if f < 6 else f - 5, random=g.rand(), reset_flag=1 if f == 6 else 0)
+        if f >= 4:
+            p = p.replace(camera_position=(1.5, 0.5, -34.0))
+        if f >= 9:
+            p = p.replace(max_bounce=5)
+        plist.append(p)
+
+    def run(b):
+        ctx = rt.host.Context(W, H, **kw)
+        for k, v in options:
+            ctx.set_option(k, v)
+        ctx.set_option("frame_batch", b)
+        assert ctx.get_option("frame_batch") == b
+        ctx.upload_scene(scene)
+        imgs = []
+        for i, p in enumerate(plist):
+            ctx.render(p, sync=False)
+            if i in (6, len(plist) - 1):
+                imgs.append(ctx.read_image())
+        ctx.close()
+        return imgs
+
+    ref, got = run(1), run(batch)
+    for a, b in zip(ref, got):
+        assert (a.view(np.uint32) == b.view(np.uint32)).all()
+
+
 @pytest.mark.parametrize("opts", [(), (("scan_waves", 1), ("cull", 0)), (("scan_waves", 2),), (("mf_chunk_quads", 4),)])
 def test_three_contexts_sharing_one_device_repeat_the_reference_image(opts, rt):
     """Round 2 found that several kernel-4 pipelines rendering CONCURRENTLY on one device come back, every few dozen to few hundred
