@@ -84,6 +84,8 @@ def main():
     ap.add_argument("--debug-bounces", type=int, default=None, help="diagnostic: override the bounce limit of the configuration (not the named workload)")
     ap.add_argument("--strip-rows", type=int, default=8, help="rows per interleaved strip (multiple of 8); 8 balances the ranks to +-3%% at N = 8, 16 to +-6%%")
     ap.add_argument("--timing-period", type=int, default=None, help="frames between kernel-timed frames (default: 4)")
+    ap.add_argument("--frame-batch", type=int, default=1, help="opt-in (rtgl option frame_batch): trace this many consecutive frames in one set of launches; the image "
+                    "(and the gather at N > 1) then follows every batch instead of every frame, bit-identical; disables the per-launch kernel timing")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sync-each-frame", action="store_true", help="diagnostic: host waits for every frame")
     ap.add_argument("--no-kernel-timing", action="store_true", help="diagnostic: no HIP events around the scan launches")
@@ -127,6 +129,10 @@ def main():
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     # HIP events around every launch of the dominant kernel, in every 4th frame: each event pair is ~3 us of launch gap, 16 pairs per frame
     # are 1.4 % of a C2 frame at N = 1 and 7 % of a rank's frame at N = 8
+    if args.frame_batch > 1:
+        args.no_kernel_timing = True                      # (a context that times its launches renders frame by frame)
+        ctx.set_option("frame_batch", args.frame_batch)
+        assert args.steps % args.frame_batch == 0, "--steps must be a multiple of --frame-batch"
     timing_period = 0 if args.no_kernel_timing else (args.timing_period or 4)
     ctx.set_option("kernel_timing", timing_period)
 
@@ -137,17 +143,24 @@ def main():
         frame_no[0] += 1
         return base.replace(frames=frame_no[0], random=rnd.rand())
 
+    submitted = [0]
+
     def step(p):
         ctx.render(p, sync=False)
-        gat.gather(overlap=world > 1)      # N > 1: snapshot + asynchronous RCCL gather, overlapped with the next frame's render
+        submitted[0] += 1
+        if submitted[0] % args.frame_batch == 0:   # (every frame unless --frame-batch: then when the batch has been submitted)
+            gat.gather(overlap=world > 1)  # N > 1: snapshot + asynchronous RCCL gather, overlapped with the next frame's render
 
     def barrier():
+        ctx.synchronize()                  # (submits what a batching context still holds back)
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         step(next_params())
+    ctx.synchronize()
+    submitted[0] = 0
     gat.finish()
     timed = [next_params() for _ in range(args.steps)]
     barrier()
@@ -249,7 +262,8 @@ def main():
             "config": {"workload": f"{args.config}: {W}x{H}, {base.max_bounce} bounces, {scene.n_triangles} triangles + "
                                    f"{scene.spheres.shape[0]} spheres, cube map {scene.env.shape[1] if scene.env is not None else 0}^2, "
                                    f"1 spp/frame progressive, dof={base.use_dof}",
-                       "parallelism": f"{world} GPU(s), {args.strip_rows}-row strips interleaved, gather to rank 0 every frame" + (" (asynchronous, overlapped with the next frame)" if world > 1 else ""),
+                       "parallelism": f"{world} GPU(s), {args.strip_rows}-row strips interleaved, gather to rank 0 every " + ("frame" if args.frame_batch == 1 else f"batch of {args.frame_batch} frames") + (" (asynchronous, overlapped with the next frame)" if world > 1 else ""),
+                       "frame_batch": args.frame_batch,
                        "kernel": ctx.get_option("kernel_in_use"), "wf_rays": ctx.get_option("wf_rays"), "wf_mode": ctx.get_option("wf_mode"), "wf_chunk": ctx.get_option("wf_chunk"), "wf_early": ctx.get_option("wf_early"), "wf_packed": ctx.get_option("wf_packed"),
                        "mf_sets": ctx.get_option("mf_sets"), "mf_group_quads": ctx.get_option("mf_group_quads"), "mf_chunk_quads": ctx.get_option("mf_chunk_quads")},
             "roofline": roof,

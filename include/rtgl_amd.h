@@ -122,7 +122,7 @@ int rtgl_upload_envmap(rtgl_context *ctx, const uint8_t *faces, int nfaces, int 
 
 /* -- per frame: replaces the uniform uploads + glDispatchCompute + glMemoryBarrier of
  * Renderer::render (src/renderer.cpp:96-134).  rtgl_render_frame enqueues on the context's stream
- * and returns; rtgl_synchronize waits. */
+ * and returns; rtgl_synchronize waits.  (Option "frame_batch" > 1: it may hold the frame back until the batch is full, see below.) */
 int rtgl_set_frame_params(rtgl_context *ctx, const rtgl_frame_params *params);
 int rtgl_render_frame(rtgl_context *ctx);
 int rtgl_synchronize(rtgl_context *ctx);
@@ -154,7 +154,12 @@ int rtgl_read_rng_state(rtgl_context *ctx, uint32_t *xyzw);    /* per local pixe
  * 0 off, 1 on the camera-ray bounce (default), 2 on every bounce), "mf_group_quads" (quads
  * sharing one local origin: a power of two up to 64; changing it rebuilds the broad-phase data at the next frame),
  * "rng_state", "counters", "kernel_timing" (0 off; N > 0: every N-th frame since the last rtgl_timing_reset carries HIP
- * event pairs around its dominant-kernel launches) */
+ * event pairs around its dominant-kernel launches), "frame_batch" (1 (default) .. 8, also RTGL_AMD_FRAME_BATCH: with B > 1 rtgl_render_frame
+ * only records the frame until B frames are waiting, then traces them in ONE set of launches and applies their results to the image in
+ * frame order -- bit-identical to frame-by-frame, B times the rays per launch (what a rank of a multi-GPU run lacks).  Every other entry
+ * point submits the waiting frames first, so the image a caller reads is always complete; frames that differ in samples, bounce limit,
+ * environment switch or background close a batch early; with "counters", "rng_state" or "kernel_timing" on, with more than one sample
+ * per frame and for scenes without triangles frames are rendered one by one) */
 int rtgl_set_option(rtgl_context *ctx, const char *key, int value);
 int rtgl_get_option(rtgl_context *ctx, const char *key, int *value);   /* also "kernel_in_use": the variant the last frame ran */
 /* elapsed GPU milliseconds of the last rtgl_render_frame (HIP events on the context's stream) */
