@@ -110,6 +110,16 @@ def test_facade_program_matches_oracle(tmp_path, rt, oracle):
     subprocess.check_call([exe, d2, str(W), str(H), str(frames), str(reset_at)], cwd=d2, env=dict(os.environ, RTGL_AMD_DEVICES="0,0,0"))
     tiled = np.fromfile(os.path.join(d2, "image.raw"), np.float32).reshape(H, W, 4)
     assert (tiled.view(np.uint32) == expected(open(os.path.join(d2, "params.raw"), "rb").read()).view(np.uint32)).all()
+    # ... and with the library batching four frames per set of launches (RTGL_AMD_FRAME_BATCH, read when the context is created): the reset
+    # frame falls inside the first batch, the last two frames are submitted by the read-back
+    d3 = os.path.join(d, "batched")
+    os.mkdir(d3)
+    for f in os.listdir(d):
+        if f.endswith((".png", ".obj")) and not f.startswith("render_"):
+            os.symlink(os.path.join(d, f), os.path.join(d3, f))
+    subprocess.check_call([exe, d3, str(W), str(H), str(frames), str(reset_at)], cwd=d3, env=dict(os.environ, RTGL_AMD_FRAME_BATCH="4"))
+    batched = np.fromfile(os.path.join(d3, "image.raw"), np.float32).reshape(H, W, 4)
+    assert (batched.view(np.uint32) == expected(open(os.path.join(d3, "params.raw"), "rb").read()).view(np.uint32)).all()
     # lossless outputs and the resumable state.  Run A renders three frames and saves; run B, a new process, loads the state
     # and renders three more: its uniforms continue the frame count (u_frames 4, 5, 6) and its image is the oracle's running mean over
     # A's image -- exactly what an uninterrupted run accumulates

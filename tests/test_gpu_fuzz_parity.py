@@ -1,4 +1,5 @@
-"""Random scenes, random cameras, random kernel-4 options against the CPU oracle, bit for bit (image and final PCG4D states):
+"""Random scenes, random cameras, random kernel-4 options against the CPU oracle, bit for bit (image and final PCG4D states; cases of
+more than one frame are rendered a second time as one batch of frames, option "frame_batch", and must give the same image):
 triangle soups (random positions, sizes from needles to scene-sized, random windings and materials), two meshes, the demo spheres on or
 off, cube map on or off, 1..8 bounces, 1..3 frames, images whose sizes are not multiples of anything, and for the scan: one / two waves
 per SIMD, static / dynamic work distribution, cull off / camera rays / every bounce, chunks of 1..32 quads, groups of 1..64 quads.
@@ -52,6 +53,16 @@ def run_cases(rt, oracle, N, seed):
             ctx.render(p)
             _, seeds_o = oracle.render(scene, p, img_o, threads=16, want_seeds=True)
         img_g = ctx.read_image(); seeds_g = ctx.read_rng_state(); ctx.close()
+        if frames > 1:                       # the same frames once more as ONE batch (option "frame_batch"; no per-frame read-outs there): same image
+            ctx = rt.host.Context(W, H)
+            for k, val in opts.items(): ctx.set_option(k, val)
+            ctx.set_option("frame_batch", frames); ctx.upload_scene(scene)
+            g = sc.GlibcRand(case)
+            for f in range(1, frames + 1): ctx.render(p0.replace(frames=f, random=g.rand()), sync=False)
+            img_b = ctx.read_image(); ctx.close()
+            if (img_b.view(np.uint32) != img_g.view(np.uint32)).any():
+                bad += 1
+                print("case", case, ": batched frames differ from frame by frame |", W, "x", H, "triangles", n1, "+", n2, "bounces", p0.max_bounce, "frames", frames, opts, flush=True)
         dw, dh = W // 8 * 8, H // 8 * 8
         neq = int((img_g.view(np.uint32) != img_o.view(np.uint32)).any(axis=2).sum()); sneq = int((seeds_g[:dh, :dw] != seeds_o[:dh, :dw]).any(axis=-1).sum()) if seeds_g.ndim == 3 else int((seeds_g[:dh, :dw] != seeds_o[:dh, :dw]).sum())
         if neq or sneq:
