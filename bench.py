@@ -87,6 +87,7 @@ def main():
     ap.add_argument("--frame-batch", type=int, default=1, help="opt-in (rtgl option frame_batch): trace this many consecutive frames in one set of launches; the image "
                     "(and the gather at N > 1) then follows every batch instead of every frame, bit-identical; disables the per-launch kernel timing")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-batched-extra", action="store_true", help="skip the second, separately reported region (four frames per set of launches)")
     ap.add_argument("--sync-each-frame", action="store_true", help="diagnostic: host waits for every frame")
     ap.add_argument("--no-kernel-timing", action="store_true", help="diagnostic: no HIP events around the scan launches")
     ap.add_argument("--cpu-rows", type=int, default=1080, help="rows of the frame the CPU baseline renders (8-row strips, uniformly strided): 1080 = the whole C2 frame, ~10 s on 16 threads")
@@ -143,12 +144,12 @@ def main():
         frame_no[0] += 1
         return base.replace(frames=frame_no[0], random=rnd.rand())
 
-    submitted = [0]
+    submitted, batch_now = [0], [args.frame_batch]
 
     def step(p):
         ctx.render(p, sync=False)
         submitted[0] += 1
-        if submitted[0] % args.frame_batch == 0:   # (every frame unless --frame-batch: then when the batch has been submitted)
+        if submitted[0] % batch_now[0] == 0:   # (every frame unless --frame-batch: then when the batch has been submitted)
             gat.gather(overlap=world > 1)  # N > 1: snapshot + asynchronous RCCL gather, overlapped with the next frame's render
 
     def barrier():
@@ -185,6 +186,39 @@ def main():
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+
+    # A second region, reported beside `value`, never as it: the same workload with FOUR frames traced per set of launches (option
+    # "frame_batch", DESIGN.md 7: bit-identical image; the image -- and at N > 1 the gather -- follows every batch instead of every frame).
+    batched = None
+    if args.frame_batch == 1 and not args.no_batched_extra and args.steps >= 8 and not args.sync_each_frame:
+        B = 4
+        kb = args.steps // B * B
+        ctx.set_option("kernel_timing", 0)
+        ctx.set_option("frame_batch", B)
+        batch_now[0], submitted[0] = B, 0
+        for _ in range(2 * B):
+            step(next_params())
+        ctx.synchronize()
+        gat.finish()
+        extra = [next_params() for _ in range(kb)]
+        barrier()
+        tb = time.perf_counter()
+        for p in extra:
+            step(p)
+        gat.finish()
+        barrier()
+        dtb = time.perf_counter() - tb
+        if world > 1:
+            tt = torch.tensor([dtb], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dtb = float(tt.item())
+        ctx.set_option("frame_batch", 1)
+        ctx.set_option("kernel_timing", timing_period)
+        batch_now[0] = 1
+        batched = {"frame_batch": B, "steps": kb, "ms_per_step": dtb / kb * 1e3, "unit": "Mpaths/s",
+                   "value": (W // 8 * 8) * (H // 8 * 8) * base.samples * kb / dtb / 1e6,
+                   "note": "same frames, four traced per set of launches (rtgl option frame_batch, opt-in, bit-identical); the image and the gather follow every batch, "
+                           "not every frame; measured after the region `value` comes from, same barriers"}
 
     # untimed: work counters of one representative frame (atomics are off in the timed region)
     ctx.set_option("counters", 1)
@@ -270,6 +304,8 @@ def main():
             "compute": compute,
             "counters_per_frame": cnt,
         }
+        if batched:
+            out["frame_batch_4"] = batched
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(rt, scene, timed[0], W, H, args.cpu_rows)
             # the reference itself cannot travel to the GPU box: its llvmpipe timing is measured in the build container by
