@@ -87,7 +87,8 @@ def main():
     ap.add_argument("--frame-batch", type=int, default=1, help="opt-in (rtgl option frame_batch): trace this many consecutive frames in one set of launches; the image "
                     "(and the gather at N > 1) then follows every batch instead of every frame, bit-identical; disables the per-launch kernel timing")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-batched-extra", action="store_true", help="skip the second, separately reported region (four frames per set of launches)")
+    ap.add_argument("--batched-extra", choices=("auto", "on", "off"), default="auto", help="the second, separately reported region (four frames per set of launches): "
+                    "auto = only at N > 1, so that a profile of the default single-GPU command holds the launches of the `value` region alone")
     ap.add_argument("--sync-each-frame", action="store_true", help="diagnostic: host waits for every frame")
     ap.add_argument("--no-kernel-timing", action="store_true", help="diagnostic: no HIP events around the scan launches")
     ap.add_argument("--cpu-rows", type=int, default=1080, help="rows of the frame the CPU baseline renders (8-row strips, uniformly strided): 1080 = the whole C2 frame, ~10 s on 16 threads")
@@ -190,7 +191,7 @@ def main():
     # A second region, reported beside `value`, never as it: the same workload with FOUR frames traced per set of launches (option
     # "frame_batch", DESIGN.md 7: bit-identical image; the image -- and at N > 1 the gather -- follows every batch instead of every frame).
     batched = None
-    if args.frame_batch == 1 and not args.no_batched_extra and args.steps >= 8 and not args.sync_each_frame:
+    if args.frame_batch == 1 and (args.batched_extra == "on" or (args.batched_extra == "auto" and world > 1)) and args.steps >= 8 and not args.sync_each_frame:
         B = 4
         kb = args.steps // B * B
         ctx.set_option("kernel_timing", 0)
