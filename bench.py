@@ -192,34 +192,39 @@ def main():
     # "frame_batch", DESIGN.md 7: bit-identical image; the image -- and at N > 1 the gather -- follows every batch instead of every frame).
     batched = None
     if args.frame_batch == 1 and (args.batched_extra == "on" or (args.batched_extra == "auto" and world > 1)) and args.steps >= 8 and not args.sync_each_frame:
-        B = 4
-        kb = args.steps // B * B
-        ctx.set_option("kernel_timing", 0)
-        ctx.set_option("frame_batch", B)
-        batch_now[0], submitted[0] = B, 0
-        for _ in range(2 * B):
-            step(next_params())
-        ctx.synchronize()
-        gat.finish()
-        extra = [next_params() for _ in range(kb)]
-        barrier()
-        tb = time.perf_counter()
-        for p in extra:
-            step(p)
-        gat.finish()
-        barrier()
-        dtb = time.perf_counter() - tb
-        if world > 1:
-            tt = torch.tensor([dtb], dtype=torch.float64, device=dev)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            dtb = float(tt.item())
-        ctx.set_option("frame_batch", 1)
-        ctx.set_option("kernel_timing", timing_period)
-        batch_now[0] = 1
-        batched = {"frame_batch": B, "steps": kb, "ms_per_step": dtb / kb * 1e3, "unit": "Mpaths/s",
-                   "value": (W // 8 * 8) * (H // 8 * 8) * base.samples * kb / dtb / 1e6,
-                   "note": "same frames, four traced per set of launches (rtgl option frame_batch, opt-in, bit-identical); the image and the gather follow every batch, "
-                           "not every frame; measured after the region `value` comes from, same barriers"}
+        try:                                               # (whatever happens here must not cost the line its `value`)
+            B = 4
+            kb = args.steps // B * B
+            ctx.set_option("kernel_timing", 0)
+            ctx.set_option("frame_batch", B)
+            batch_now[0], submitted[0] = B, 0
+            for _ in range(2 * B):
+                step(next_params())
+            ctx.synchronize()
+            gat.finish()
+            extra = [next_params() for _ in range(kb)]
+            barrier()
+            tb = time.perf_counter()
+            for p in extra:
+                step(p)
+            gat.finish()
+            barrier()
+            dtb = time.perf_counter() - tb
+            if world > 1:
+                tt = torch.tensor([dtb], dtype=torch.float64, device=dev)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                dtb = float(tt.item())
+            ctx.set_option("frame_batch", 1)
+            ctx.set_option("kernel_timing", timing_period)
+            batch_now[0] = 1
+            batched = {"frame_batch": B, "steps": kb, "ms_per_step": dtb / kb * 1e3, "unit": "Mpaths/s",
+                       "value": (W // 8 * 8) * (H // 8 * 8) * base.samples * kb / dtb / 1e6,
+                       "note": "same frames, four traced per set of launches (rtgl option frame_batch, opt-in, bit-identical); the image and the gather follow every batch, "
+                               "not every frame; measured after the region `value` comes from, same barriers"}
+        except Exception as e:                              # noqa: BLE001
+            batched = {"error": f"{type(e).__name__}: {e}"}
+            ctx.set_option("frame_batch", 1)
+            batch_now[0] = 1
 
     # untimed: work counters of one representative frame (atomics are off in the timed region)
     ctx.set_option("counters", 1)
