@@ -13,7 +13,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def render(rt, cfg_name, frames=1, options=(), tiling=None, counters=False):
+def render(rt, cfg_name, frames=1, options=(), tiling=None, counters=False, sync=True):
     sc = rt.scenes
     cfg = sc.CONFIGS[cfg_name]
     W, H = cfg["width"], cfg["height"]
@@ -28,7 +28,7 @@ def render(rt, cfg_name, frames=1, options=(), tiling=None, counters=False):
     plist = []
     for f in range(1, frames + 1):
         p = cfg["params"]().replace(frames=f, random=g.rand())
-        ctx.render(p)
+        ctx.render(p, sync=sync)
         plist.append(p)
     img = ctx.read_image()
     cnt = ctx.counters() if counters else None
@@ -50,6 +50,22 @@ def test_c2_counters(c2_reference_image, rt):
     assert cnt["triangle_tests"] == cnt["segments"] * scene.n_triangles
     assert 0 < cnt["env_lookups"] <= px
     assert np.isfinite(img).all() and (img[..., 3] == 1.0).all()
+
+
+def test_c2_batched_frames_identical(c2_reference_image, rt):
+    """Option "frame_batch": the two frames of the reference render traced in ONE set of launches (4.1 M camera rays) -- same image."""
+    img = render(rt, "C2", frames=2, options=(("frame_batch", 2),), sync=False)[0]
+    neq = int((img.view(np.uint32) != c2_reference_image[0].view(np.uint32)).any(axis=2).sum())
+    assert neq == 0, f"{neq} pixels differ"
+
+
+@pytest.mark.parametrize("cfg_name,batch", [("C4", 2), ("C5", 3)])
+def test_c4_c5_batched_frames_identical(cfg_name, batch, rt):
+    """... and at 100,000 triangles (work claimed dynamically) and at 3840 x 2160 / 16 bounces (25 M camera rays in a batch of three)."""
+    one = render(rt, cfg_name, frames=batch)[0]
+    got = render(rt, cfg_name, frames=batch, options=(("frame_batch", batch),), sync=False)[0]
+    neq = int((got.view(np.uint32) != one.view(np.uint32)).any(axis=2).sum())
+    assert neq == 0, f"{neq} pixels differ"
 
 
 @pytest.mark.parametrize("variant", [(0, 0, 1, 1024), (1, 1, 2, 1024), (2, 0, 2, 512), (2, 1, 8, 256), (2, 1, 1, 2560), (4, 32, 2, 32), (4, 4, 2, 32), (4, 1, 2, 7), (4, 64, 2, 20)])
