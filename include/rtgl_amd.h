@@ -154,7 +154,7 @@ int rtgl_read_rng_state(rtgl_context *ctx, uint32_t *xyzw);    /* per local pixe
  * 0 off, 1 on the camera-ray bounce (default), 2 on every bounce), "mf_group_quads" (quads
  * sharing one local origin: a power of two up to 64; changing it rebuilds the broad-phase data at the next frame),
  * "rng_state", "counters", "kernel_timing" (0 off; N > 0: every N-th frame since the last rtgl_timing_reset carries HIP
- * event pairs around its dominant-kernel launches), "frame_batch" (1 (default) .. 8, also RTGL_AMD_FRAME_BATCH: with B > 1 rtgl_render_frame
+ * event pairs around its dominant-kernel launches), "frame_batch" (1 (default) .. 16, also RTGL_AMD_FRAME_BATCH: with B > 1 rtgl_render_frame
  * only records the frame until B frames are waiting, then traces them in ONE set of launches and applies their results to the image in
  * frame order -- bit-identical to frame-by-frame, B times the rays per launch (what a rank of a multi-GPU run lacks).  Every other entry
  * point submits the waiting frames first, so the image a caller reads is always complete; frames that differ in samples, bounce limit,

@@ -60,7 +60,7 @@ struct WaveBuffers {
     uint32_t batch_px;            //   a finished path leaves its radiance in batch_rad[frame slot * batch_px + pixel] (the slot rides in the top
                                   //   four bits of the path's pixel word), resolve_batch_kernel folds the slots into the image in frame order
 };
-constexpr uint32_t kBatchMax = 8u;            // frames per batch
+constexpr uint32_t kBatchMax = 16u;           // frames per batch (the slot has four bits)
 constexpr uint32_t kBatchPixelMask = 0x0FFFFFFFu;
 struct BatchInfo { uint32_t n; int32_t frames[kBatchMax]; int32_t reset[kBatchMax]; };
 

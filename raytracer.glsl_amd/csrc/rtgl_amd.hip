@@ -1395,7 +1395,7 @@ extern "C" int rtgl_set_option(rtgl_context *ctx, const char *key, int value)
         if (value < 0 || value > 2) return fail(ctx, RTGL_ERR_INVALID, "scan_dynamic must be 0 (chosen by the mesh), 1 (static) or 2 (dynamic)");
         ctx->opt_scan_dynamic = value;
     } else if (!strcmp(key, "frame_batch")) {
-        if (value < 1 || value > (int)kBatchMax) return fail(ctx, RTGL_ERR_INVALID, "frame_batch (consecutive frames traced in one set of launches) must be 1..8");
+        if (value < 1 || value > (int)kBatchMax) return fail(ctx, RTGL_ERR_INVALID, "frame_batch (consecutive frames traced in one set of launches) must be 1..16");
         ctx->opt_frame_batch = value;
     } else if (!strcmp(key, "cull")) {
         if (value < 0 || value > 2) return fail(ctx, RTGL_ERR_INVALID, "cull must be 0 (off), 1 (camera rays) or 2 (every bounce)");

@@ -249,7 +249,7 @@ def test_multi_device_context_through_the_c_abi_matches_single_context(devices, 
 
 @pytest.mark.parametrize("batch,kw,options", [
     (4, {}, ()), (3, {"rank": 1, "world": 3, "strip_rows": 8}, ()), (2, {"devices": [0, 0], "strip_rows": 8}, ()), (8, {}, (("kernel", 2),)),
-    (4, {}, (("scan_dynamic", 2), ("cull", 2))), (2, {}, (("kernel", 1),))])
+    (4, {}, (("scan_dynamic", 2), ("cull", 2))), (2, {}, (("kernel", 1),)), (16, {}, ())])
 def test_batched_frames_equal_frames_rendered_one_by_one(batch, kw, options, rt):
     """Option "frame_batch" = B: rtgl_render_frame holds frames back until B are waiting, then traces them in ONE set of launches (queues B times as
     long, the frame's slot in the top bits of the pixel word, radiance parked per slot, the running mean applied in frame order by
