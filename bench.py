@@ -87,7 +87,7 @@ def main():
     ap.add_argument("--frame-batch", type=int, default=1, help="opt-in (rtgl option frame_batch): trace this many consecutive frames in one set of launches; the image "
                     "(and the gather at N > 1) then follows every batch instead of every frame, bit-identical; disables the per-launch kernel timing")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--batched-extra", choices=("auto", "on", "off"), default="auto", help="the second, separately reported region (four frames per set of launches): "
+    ap.add_argument("--batched-extra", choices=("auto", "on", "off"), default="auto", help="the second, separately reported region (2 x N frames per set of launches): "
                     "auto = only at N > 1, so that a profile of the default single-GPU command holds the launches of the `value` region alone")
     ap.add_argument("--sync-each-frame", action="store_true", help="diagnostic: host waits for every frame")
     ap.add_argument("--no-kernel-timing", action="store_true", help="diagnostic: no HIP events around the scan launches")
@@ -188,12 +188,12 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
-    # A second region, reported beside `value`, never as it: the same workload with FOUR frames traced per set of launches (option
+    # A second region, reported beside `value`, never as it: the same workload with 2 x N (at most 16) frames traced per set of launches (option
     # "frame_batch", DESIGN.md 7: bit-identical image; the image -- and at N > 1 the gather -- follows every batch instead of every frame).
     batched = None
     if args.frame_batch == 1 and (args.batched_extra == "on" or (args.batched_extra == "auto" and world > 1)) and args.steps >= 8 and not args.sync_each_frame:
         try:                                               # (whatever happens here must not cost the line its `value`)
-            B = 4
+            B = min(2 * world, 16)                         # a rank then launches what two whole frames are to a single GPU
             kb = args.steps // B * B
             ctx.set_option("kernel_timing", 0)
             ctx.set_option("frame_batch", B)
@@ -219,7 +219,7 @@ def main():
             batch_now[0] = 1
             batched = {"frame_batch": B, "steps": kb, "ms_per_step": dtb / kb * 1e3, "unit": "Mpaths/s",
                        "value": (W // 8 * 8) * (H // 8 * 8) * base.samples * kb / dtb / 1e6,
-                       "note": "same frames, four traced per set of launches (rtgl option frame_batch, opt-in, bit-identical); the image and the gather follow every batch, "
+                       "note": f"same frames, {B} traced per set of launches (rtgl option frame_batch, opt-in, bit-identical); the image and the gather follow every batch, "
                                "not every frame; measured after the region `value` comes from, same barriers"}
         except Exception as e:                              # noqa: BLE001
             batched = {"error": f"{type(e).__name__}: {e}"}
@@ -311,7 +311,7 @@ def main():
             "counters_per_frame": cnt,
         }
         if batched:
-            out["frame_batch_4"] = batched
+            out["frame_batched"] = batched
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(rt, scene, timed[0], W, H, args.cpu_rows)
             # the reference itself cannot travel to the GPU box: its llvmpipe timing is measured in the build container by
