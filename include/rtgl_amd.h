@@ -159,7 +159,7 @@ int rtgl_read_rng_state(rtgl_context *ctx, uint32_t *xyzw);    /* per local pixe
  * frame order -- bit-identical to frame-by-frame, B times the rays per launch (what a rank of a multi-GPU run lacks).  Every other entry
  * point submits the waiting frames first, so the image a caller reads is always complete; frames that differ in samples, bounce limit,
  * environment switch or background close a batch early; with "counters", "rng_state" or "kernel_timing" on, with more than one sample
- * per frame and for scenes without triangles frames are rendered one by one) */
+ * per frame and for scenes without triangles frames are rendered one by one; rtgl_destroy drops frames that are still waiting) */
 int rtgl_set_option(rtgl_context *ctx, const char *key, int value);
 int rtgl_get_option(rtgl_context *ctx, const char *key, int *value);   /* also "kernel_in_use": the variant the last frame ran */
 /* elapsed GPU milliseconds of the last rtgl_render_frame (HIP events on the context's stream) */
