@@ -290,6 +290,61 @@ def test_batched_frames_equal_frames_rendered_one_by_one(batch, kw, options, rt)
         assert (a.view(np.uint32) == b.view(np.uint32)).all()
 
 
+@pytest.mark.parametrize("seed", range(6))
+def test_random_call_sequences_with_and_without_batching_agree(seed, rt):
+    """The deferral of option "frame_batch" against every other entry point: the same random sequence of calls -- frames with changing
+    camera, bounce limit, environment switch and reset flag, read-backs (f32 and u8), image clears and preloads, new scenes, option
+    changes (including the batch size itself), counters switched on and off, synchronisations -- on a context that batches and on one
+    that does not: every read-back equal bit for bit, in order."""
+    sc = rt.scenes
+    rng = np.random.default_rng(100 + seed)
+    W, H = 8 * int(rng.integers(6, 20)), 8 * int(rng.integers(4, 12)) + int(rng.integers(0, 8))
+    scenes = [sc.scene_mesh(20, 8, env_size=16), sc.scene_mesh(9, 14, env_size=16)]
+    base = sc.params_c2()
+    ops = []
+    frame = 0
+    for _ in range(60):
+        r = rng.random()
+        if r < 0.62:
+            frame += 1
+            ops.append(("render", dict(frames=frame, random=int(rng.integers(0, 2**31 - 1)), reset_flag=int(rng.random() < 0.08), max_bounce=int(rng.choice([8, 8, 8, 3])),
+                                       use_envmap=int(rng.random() < 0.9), camera_position=(float(rng.choice([0.0, 1.5])), 0.5, -34.0))))
+        elif r < 0.72: ops.append(("read", None))
+        elif r < 0.76: ops.append(("read_u8", None))
+        elif r < 0.80: ops.append(("sync", None))
+        elif r < 0.84: ops.append(("scene", int(rng.integers(0, 2))))
+        elif r < 0.88: ops.append(("option", ("cull", int(rng.integers(0, 3)))))
+        elif r < 0.92: ops.append(("batch", int(rng.integers(1, 17))))
+        elif r < 0.95: ops.append(("counters", int(rng.integers(0, 2))))
+        elif r < 0.975: ops.append(("clear", None))
+        else: ops.append(("preload", int(rng.integers(0, 1000))))
+    ops.append(("read", None))
+
+    def run(batching):
+        ctx = rt.host.Context(W, H)
+        ctx.set_option("frame_batch", 5 if batching else 1)
+        ctx.upload_scene(scenes[0])
+        out = []
+        for op, arg in ops:
+            if op == "render": ctx.render(base.replace(**arg), sync=False)
+            elif op == "read": out.append(ctx.read_image())
+            elif op == "read_u8": out.append(ctx.read_image_u8(flip=True))
+            elif op == "sync": ctx.synchronize()
+            elif op == "scene": ctx.upload_scene(scenes[arg])
+            elif op == "option": ctx.set_option(*arg)
+            elif op == "batch": ctx.set_option("frame_batch", arg if batching else 1)
+            elif op == "counters": ctx.set_option("counters", arg)
+            elif op == "clear": ctx.clear_image()
+            elif op == "preload": ctx.write_image(np.random.default_rng(arg).random((H, W, 4), dtype=np.float32))
+        ctx.close()
+        return out
+
+    ref, got = run(False), run(True)
+    assert len(ref) == len(got) and len(ref) >= 1
+    for k, (a, b) in enumerate(zip(ref, got)):
+        assert a.dtype == b.dtype and (a.view(np.uint8) == b.view(np.uint8)).all(), f"read-back {k} differs"
+
+
 @pytest.mark.parametrize("opts", [(), (("scan_waves", 1), ("cull", 0)), (("scan_waves", 2),), (("mf_chunk_quads", 4),)])
 def test_three_contexts_sharing_one_device_repeat_the_reference_image(opts, rt):
     """Round 2 found that several kernel-4 pipelines rendering CONCURRENTLY on one device come back, every few dozen to few hundred
