@@ -68,7 +68,7 @@ def cpu_baseline(rt, scene, params, width, height, budget_rows=256):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=400)      # ~2.5 s of timed region on C2: clocks settle, the driver's SMI sampler sees the run
+    ap.add_argument("--steps", type=int, default=800)      # 2.7 s of timed region on C2: clocks settle, the driver's SMI sampler sees the run
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", default="C2", help="C2 (headline), C4, C5 or C1")
     ap.add_argument("--kernel", type=int, default=None, help="kernel variant override (rtgl_set_option kernel)")
