@@ -158,7 +158,14 @@ static inline void pcg4d(u4 *v) /* :140-146 */
 typedef struct {
     u4 seed;
     oracle_counters *cnt;
+    size_t pix;              /* py * W + px of the pixel being traced (ray dump only) */
 } rng_t;
+
+/* Diagnostics (tools/diagnostics/cull_emulation.py): when set, every path that reaches bounce g_dump_bounce leaves the ray it enters
+ * that bounce with (o.xyz, d.xyz) in g_dump[6 * pixel]; the caller pre-fills the buffer with NaN.  Not used by any test. */
+static float *g_dump = NULL;
+static uint32_t g_dump_bounce = 0;
+void oracle_set_ray_dump(float *buf, uint32_t bounce) { g_dump = buf; g_dump_bounce = bounce; }
 
 static inline float orand(rng_t *r) /* :148-152; float(0xffffffffu) rounds to 2^32 */
 {
@@ -381,6 +388,7 @@ static v3 trace_path(const oracle_scene *sc, const oracle_params *P, v3 o, v3 d,
     cnt->paths++;
     for (uint32_t bounce = 0; bounce < P->max_bounce; bounce++) {
         cnt->segments++;
+        if (g_dump && bounce == g_dump_bounce) { float *q = g_dump + 6 * rng->pix; q[0] = o.x; q[1] = o.y; q[2] = o.z; q[3] = d.x; q[4] = d.y; q[5] = d.z; }
         hit_t h1, h2;
         memset(&h1, 0, sizeof h1); memset(&h2, 0, sizeof h2);
         h1.t = ORACLE_INF; h2.t = ORACLE_INF;
@@ -455,7 +463,7 @@ static void render_pixel(const oracle_scene *sc, const oracle_params *P, int W, 
                          float *image, uint32_t *seed_out, oracle_counters *cnt)
 {
     rng_t rng;
-    rng.cnt = cnt;
+    rng.cnt = cnt; rng.pix = (size_t)py * (size_t)W + (size_t)px;
     rng.seed.x = (uint32_t)px; rng.seed.y = (uint32_t)py; rng.seed.z = (uint32_t)P->random;
     rng.seed.w = (uint32_t)px + (uint32_t)py + (uint32_t)P->random; /* init_rand :135-138 */
     float fw = (float)W, fh = (float)H;

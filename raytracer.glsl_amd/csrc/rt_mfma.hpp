@@ -66,7 +66,7 @@ struct MfView {
     // i.e. F~ = (e_hi + e_lo).cv_hi + (m_hi + m_lo).d_hi + m_hi.d_lo  (+ bias, -3e38 on padding rows, 0 otherwise)
     const uint4 *A;
     uint32_t *dbg_log;       // diagnostics only
-    const MfCull *cull;      // one record per quad (packet culling)
+    const MfCull *cull;      // one record per tile (packet culling)
     const TriEdges *edges_s; const TriPlane *planes_s;   // the exact test's records in STORAGE order (copies of SceneView's, gathered at
                              // upload): the narrow phase reads them by storage position, one dependent round trip less than through `order`
     const uint32_t *order;   // storage position -> visit index.  Triangles are stored in Morton order of their centroids
@@ -204,45 +204,61 @@ __device__ __forceinline__ float mf_margin(const MfGroup &G, float ncv, float no
 }
 
 // ---- packet culling (the reference's disabled AABB cull, raytracer.glsl:258-270,288-292, done rigorously) ----------
-// A wave scans 128 rays against a chunk of quads (40 triangles each).  A quad may be skipped for the whole wave when EVERY ray of
-// the wave is certified to be rejected by the reference's own test for EVERY triangle of the quad.  "The ray misses the quad's
-// bounding volume" is not such a certificate: the reference tests LINES, and a line lying in (or within rounding noise of) the
-// plane of a far-away triangle has all three edge functions at +-noise, so the reference may accept it with an arbitrary t.  The
-// certificate therefore lives in edge-function space.  With N = (v1-v0) x (v2-v0), p = line /\ plane and beta_k the barycentric
-// coordinates of p, the exact edge functions are F_k = -(d.N) beta_k (F_0 = d.((o-v0) x e0) = d.((p-v0) x e0)), so
-//   * front facing (d.N < 0): p at distance >= delta from the triangle  =>  some beta_k <= -delta s / h_max, s = sin(smallest
-//     angle / 2), h_max the largest height (closest point on an edge: the edge's own coordinate; at a vertex: the normal cone of
-//     the vertex gives cos >= sin(angle/2) for one of the two edges)  =>  min_k F_k <= -|d.N| delta s / h_max;
-//   * back facing (d.N > 0): sum beta = 1  =>  max beta >= 1/3  =>  min_k F_k <= -(d.N)/3.
-// The reference rejects an edge whenever its exact value is <= -(7w E|o||d| + 6w Pw|d|), w = 2^-24 (mf_margin, part (2)); so
-//   |d^.N_T| min(1/3, delta s_T / h_T)  >=  2^-20 (E |o| + Pw)          for every triangle T of the quad, every ray of the wave
-// certifies the skip (d^ = d/|d|: both sides scale with |d|).  Per quad the record below bounds the left side from below for any
-// line that misses the quad's bounding sphere (C, R) by delta and whose direction makes |cos| >= cmin with every triangle normal
-// (the unit normals of the quad lie in the box [nlo, nhi]: interval arithmetic on D.n^ -- a bumpy height field spreads its
-// normals by +-50 degrees inside 40 triangles, far too much for a cone, but mostly across the viewing direction); per wave the
-// kernel bounds its rays by an origin sphere (O, ro) and a direction cone (D, sigma = max |d^ - D|):
-//   delta >= |(C-O) x D| - |C-O| sigma - ro - R,     cmin >= min |[D.n^]| - sigma  (0 not inside the interval),     |o| <= |O| + ro.
-// Degenerate or non-finite triangles make the record unusable (Nmin = 0 or NaN: the comparison fails, the quad is scanned).
+// A wave scans a granule of 128 rays against a chunk of tiles (10 triangles each).  A tile may be skipped for the whole granule when
+// EVERY ray of the granule is certified to be rejected by the reference's own test for EVERY triangle of the tile.  "The ray misses
+// the tile's bounding volume" is not such a certificate: the reference tests LINES, and a line lying in (or within rounding noise of)
+// the plane of a far-away triangle has all three edge functions at +-noise, so the reference may accept it with an arbitrary t.  The
+// certificates therefore live in edge-function space.  Notation: triangle T with vertices v_k, edges e_k = v_{k+1} - v_k,
+// N = e_0 x (v_2 - v_0), unit normal n^, centroid G, longest edge l_max, smallest altitude h_min (|N| = l_max h_min); line (o, d);
+// F_k = d.((o - v_k) x e_k) the exact edge functions.  The reference rejects an edge whenever its exact value is
+// <= -(7u E|o||d| + 6u Pw|d|), u = 2^-24 (mf_margin, part (2)); noise := 2^-20 (E|o| + Pw) per unit |d| bounds that from above.
+//
+//   (A) plane form.  With p = line /\ plane and beta_k the barycentric coordinates of p: F_k = -(d.N) beta_k.
+//       front facing (d.N < 0): p at distance >= delta from the triangle  =>  some beta_k <= -delta s / h_max (s = sin(smallest
+//       angle / 2), h_max the largest height)  =>  min_k F_k <= -|d.N| delta s / h_max;  back facing: max beta >= 1/3.
+//       Certified when  |d^.N| min(1/3, delta s / h_max) >= noise.
+//   (K) back faces.  d.N > 0: sum beta = 1  =>  max beta >= 1/3  =>  min_k F_k <= -(d.N)/3, wherever the line is.
+//       Certified when  (d^.N)/3 >= noise.  (Secondary rays leave the front side of a single-sided mesh: for most of them most of
+//       the mesh is back-facing.)
+//   (B) moment form.  For any point q of the line, (q - v_k) x e_k = (q - G) x e_k - N/3, so with the moment of the line about the
+//       centroid, w = d x (o - G):   F_k = e_k.w - (d.N)/3.   sum e_k = 0  =>  min_k e_k.w <= -mu/2 with mu = max_k |e_k.w|; the
+//       e_k lie in the plane, so mu = max_k |e_k.w_p| (w_p = w - (w.n^) n^) = the extent of the triangle along w_p >= h_min |w_p|;
+//       and d _|_ w  =>  |d^.n^| <= |w_p| / |w|.  Hence
+//           min_k F_k <= -h_min |w_p| / 2 + |N| |d^.n^| / 3 <= -h_min |w_p| (1/2 - l_max / (3 |w|)),        |w| = distance(line, G)
+//       Certified when  h_min |w_p| (1/2 - l_max / (3 |w|)) >= noise  and  |w| > 4/3 l_max.  |w_p| = |d^.n^| |p - G|: this is (A) with
+//       the distance measured IN the plane, where a grazing line is far from the triangle -- what (A) loses to its separate guard.
+//
+// Per tile the record below bounds the right quantities for all 10 triangles: bounding sphere (C, R) of the vertices, Rc >= |G - C|,
+// the unit normals as a rectangle in gnomonic coordinates about an axis a -- n^ = (a + x t1 + y t2) / sqrt(1 + x^2 + y^2), |x| <= X,
+// |y| <= Y, (a, t1, t2) orthonormal, t1 along the direction the normals spread most (a curved strip of a height field spreads its
+// normals by +-30 degrees one way and +-5 the other: a cone around a would be six times the area) --, Nmin = min |N|, shape = min
+// s / h_max, hmin, lmax, E, Pw.  Per granule the kernel bounds the rays by an origin sphere (O, ro) and a direction cone (unit D,
+// sigma = max |d^ - D|).  Then for every line of the granule and triangle of the tile
+//       |d^.n^ - D.n^| <= sigma;     delta >= |(C - O) x D| - |C - O| sigma - ro - R;     |o| <= |O| + ro;
+//       |w - W| <= ro + Rc + sigma |O - C| =: slack,   W = D x (O - C);     |w_p| >= sqrt(|W|^2 - M^2) - slack,  M >= max |W.n^|.
+// Degenerate or non-finite triangles, or normals spread over more than ~84 degrees, make the record unusable (Nmin = 0: every
+// comparison fails, the tile is scanned).  The theory is tested on the CPU against the reference's own fp32 test
+// (tests/test_cull_certificate.py restates the record and the three certificates in numpy).
 struct alignas(16) MfCull {
-    float cx, cy, cz, R;          // bounding sphere of the quad's vertices
-    float nlx, nly, nlz;          // box of the unit normals
-    float nhx, nhy, nhz;
-    float Nmin, shape;            // min |N_T|, min s_T / h_max,T
-    float E, Pw;                  // max |e_k|, max |v_a||v_b|  (the reference's own rounding, world coordinates)
-    float pad[2];
+    float cx, cy, cz, R;          // bounding sphere of the tile's vertices
+    float ax, ay, az, Rc;         // axis of the normals; radius of the centroids about (cx, cy, cz)
+    float t1x, t1y, t1z, X;       // tangent frame and the half extents of the normals' gnomonic coordinates
+    float t2x, t2y, t2z, Y;
+    float Nmin, shape, hmin, lmax;
+    float E, Pw, inv_len, pad;    // inv_len <= 1 / sqrt(1 + X^2 + Y^2)
 };
-static_assert(sizeof(MfCull) == 64, "one LDS row of four uint4 per quad");
+static_assert(sizeof(MfCull) == 96, "six uint4 per tile");
 
 __device__ __forceinline__ float wave_sum(float x) { for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off); return x; }
 
-// one wave per quad, one lane per triangle (storage order)
+// one wave per tile, one lane per triangle (storage order)
 __global__ void __launch_bounds__(64) prepare_cull_kernel(const float4 *__restrict__ vertices, const uint32_t *__restrict__ visit_tri,
-                                                          const uint32_t *__restrict__ order, uint32_t n_visits, uint32_t n_quads, MfCull *__restrict__ out)
+                                                          const uint32_t *__restrict__ order, uint32_t n_visits, uint32_t n_tiles, MfCull *__restrict__ out)
 {
     const uint32_t q = blockIdx.x, lane = threadIdx.x;
-    if (q >= n_quads) return;
-    const uint32_t pos = q * kMfQuadTris + lane;
-    const bool have = lane < (uint32_t)kMfQuadTris && pos < n_visits;
+    if (q >= n_tiles) return;
+    const uint32_t pos = q * kMfTileTris + lane;
+    const bool have = lane < (uint32_t)kMfTileTris && pos < n_visits;
     const float inf = __builtin_inff();
     f3 w[3] = {mk(0.0f, 0.0f, 0.0f), mk(0.0f, 0.0f, 0.0f), mk(0.0f, 0.0f, 0.0f)};
     if (have) { const uint32_t tri = visit_tri[order[pos]]; for (int k = 0; k < 3; ++k) { const float4 p = vertices[3 * (size_t)tri + k]; w[k] = mk(p.x, p.y, p.z); } }
@@ -256,7 +272,7 @@ __global__ void __launch_bounds__(64) prepare_cull_kernel(const float4 *__restri
     lo = mk(wave_min(lo.x), wave_min(lo.y), wave_min(lo.z));
     hi = mk(wave_max(hi.x), wave_max(hi.y), wave_max(hi.z));
     const f3 c = mk(0.5f * lo.x + 0.5f * hi.x, 0.5f * lo.y + 0.5f * hi.y, 0.5f * lo.z + 0.5f * hi.z);
-    float R = 0.0f, E = 0.0f, Pw = 0.0f, Nmin = inf, shape = inf;
+    float R = 0.0f, Rc = 0.0f, E = 0.0f, Pw = 0.0f, Nmin = inf, shape = inf, hmin = inf;
     f3 nh = mk(0.0f, 0.0f, 0.0f);
     if (have) {
         const f3 e0 = w[1] - w[0], e1 = w[2] - w[1], e2 = w[0] - w[2];
@@ -264,6 +280,8 @@ __global__ void __launch_bounds__(64) prepare_cull_kernel(const float4 *__restri
         const float nn = __builtin_sqrtf(dot3(N, N));
         const float l0 = __builtin_sqrtf(dot3(e0, e0)), l1 = __builtin_sqrtf(dot3(e1, e1)), l2 = __builtin_sqrtf(dot3(e2, e2));
         for (int k = 0; k < 3; ++k) { const f3 r = w[k] - c; R = fmaxf(R, __builtin_sqrtf(dot3(r, r))); }
+        { const f3 g = mk((w[0].x + w[1].x + w[2].x) * (1.0f / 3.0f), (w[0].y + w[1].y + w[2].y) * (1.0f / 3.0f), (w[0].z + w[1].z + w[2].z) * (1.0f / 3.0f)) - c;
+          Rc = __builtin_sqrtf(dot3(g, g)); }
         E = fmaxf(l0, fmaxf(l1, l2));
         const float a0 = __builtin_sqrtf(dot3(w[0], w[0])), a1 = __builtin_sqrtf(dot3(w[1], w[1])), a2 = __builtin_sqrtf(dot3(w[2], w[2]));
         Pw = fmaxf(a0 * a1, fmaxf(a1 * a2, a2 * a0));
@@ -276,19 +294,101 @@ __global__ void __launch_bounds__(64) prepare_cull_kernel(const float4 *__restri
         const float lmin = fminf(l0, fminf(l1, l2));
         shape = (nn > 0.0f) ? 0.999f * s * lmin / nn : 0.0f;                 // s / h_max, h_max = |N| / shortest edge
         if (!(shape == shape)) shape = 0.0f;
+        hmin = (E > 0.0f) ? 0.999f * nn / E : 0.0f;                          // smallest altitude = |N| / longest edge
+        if (!(hmin == hmin)) hmin = 0.0f;
     }
-    R = wave_max(R); E = wave_max(E); Pw = wave_max(Pw); Nmin = wave_min(Nmin); shape = wave_min(shape);
-    f3 nl = have ? nh : mk(inf, inf, inf), nu = have ? nh : mk(-inf, -inf, -inf);
-    nl = mk(wave_min(nl.x), wave_min(nl.y), wave_min(nl.z)); nu = mk(wave_max(nu.x), wave_max(nu.y), wave_max(nu.z));
-    bad = __any(bad);
+    R = wave_max(R); Rc = wave_max(Rc); E = wave_max(E); Pw = wave_max(Pw); Nmin = wave_min(Nmin); shape = wave_min(shape); hmin = wave_min(hmin);
+    bad = __any(bad) || __any(have && !(nh.x == nh.x && nh.y == nh.y && nh.z == nh.z));
+    // axis of the normals: their normalised sum
+    f3 a = mk(wave_sum(have ? nh.x : 0.0f), wave_sum(have ? nh.y : 0.0f), wave_sum(have ? nh.z : 0.0f));
+    const float al = __builtin_sqrtf(dot3(a, a));
+    a = (al > 0.0f) ? mk(a.x / al, a.y / al, a.z / al) : mk(0.0f, 0.0f, 1.0f);
+    const float ca = have ? dot3(nh, a) : 1.0f;
+    bad |= !(al > 0.0f) || __any(have && !(ca > 0.1f));                       // normals spread over more than ~84 degrees: no rectangle
+    // gnomonic coordinates of the normals in a first tangent basis (b1, b2); t1 = the principal axis of their second moments
+    const f3 ref = (fabsf(a.x) < 0.7f) ? mk(1.0f, 0.0f, 0.0f) : mk(0.0f, 1.0f, 0.0f);
+    f3 b1 = cross3(a, ref);
+    { const float bl = __builtin_sqrtf(dot3(b1, b1)); b1 = mk(b1.x / bl, b1.y / bl, b1.z / bl); }
+    const f3 b2 = cross3(a, b1);
+    const float ica = 1.0f / fmaxf(ca, 0.1f);
+    const float gu = have ? dot3(nh, b1) * ica : 0.0f, gv = have ? dot3(nh, b2) * ica : 0.0f;
+    const float suu = wave_sum(gu * gu), suv = wave_sum(gu * gv), svv = wave_sum(gv * gv);
+    const float phi = 0.5f * atan2f(2.0f * suv, suu - svv);                  // (any frame is valid: only the tightness of the rectangle depends on phi)
+    const float cp = cosf(phi), sp = sinf(phi);
+    f3 t1 = mk(cp * b1.x + sp * b2.x, cp * b1.y + sp * b2.y, cp * b1.z + sp * b2.z);
+    { const float tl = __builtin_sqrtf(dot3(t1, t1)); t1 = mk(t1.x / tl, t1.y / tl, t1.z / tl); }
+    f3 t2 = cross3(a, t1);
+    { const float tl = __builtin_sqrtf(dot3(t2, t2)); t2 = mk(t2.x / tl, t2.y / tl, t2.z / tl); }
+    const float X = wave_max(have ? fabsf(dot3(nh, t1) * ica) : 0.0f), Y = wave_max(have ? fabsf(dot3(nh, t2) * ica) : 0.0f);
     if (lane != 0) return;
     MfCull rec;
     rec.cx = c.x; rec.cy = c.y; rec.cz = c.z; rec.R = R * 1.0001f + 1e-30f;
-    rec.nlx = nl.x - 1e-6f; rec.nly = nl.y - 1e-6f; rec.nlz = nl.z - 1e-6f; rec.nhx = nu.x + 1e-6f; rec.nhy = nu.y + 1e-6f; rec.nhz = nu.z + 1e-6f;
-    rec.Nmin = bad ? 0.0f : Nmin * 0.999f; rec.shape = bad ? 0.0f : shape;
+    rec.ax = a.x; rec.ay = a.y; rec.az = a.z; rec.Rc = Rc * 1.0001f + 1e-30f;
+    rec.t1x = t1.x; rec.t1y = t1.y; rec.t1z = t1.z; rec.X = X * 1.001f + 1e-5f;
+    rec.t2x = t2.x; rec.t2y = t2.y; rec.t2z = t2.z; rec.Y = Y * 1.001f + 1e-5f;
+    bad |= !(rec.X < 16.0f) || !(rec.Y < 16.0f);
+    rec.Nmin = bad ? 0.0f : Nmin * 0.999f; rec.shape = bad ? 0.0f : shape; rec.hmin = bad ? 0.0f : hmin; rec.lmax = E * 1.001f;
     rec.E = E * 1.001f; rec.Pw = Pw * 1.001f;
-    rec.pad[0] = rec.pad[1] = 0.0f;
+    rec.inv_len = 0.9999f / __builtin_sqrtf(1.0f + rec.X * rec.X + rec.Y * rec.Y);
+    rec.pad = 0.0f;
     out[q] = rec;
+}
+
+// The packet of one granule and the three certificates against one tile record (the derivations are above).  Every bound carries
+// explicit slack (1e-4 relative, 1e-5 / 1e-6 absolute) against its own fp32 evaluation, which uses 1-ulp v_rsq / v_sqrt.
+struct MfPacket { f3 O, D; float ro, sigma, On; };
+
+// upper bound of max over the record's normals of (w . n^), n^ = (a + x t1 + y t2) / sqrt(1 + x^2 + y^2) in the rectangle: the maximum
+// of f(x, y) = (wa + x w1 + y w2) / sqrt(1 + x^2 + y^2) over a rectangle is |w| if the rectangle contains (w1, w2) / wa (wa > 0), else it
+// sits on the boundary: a corner, or the stationary point of an edge (edge x = X: y* = w2 (1 + X^2) / A, A = wa + X w1, value
+// sqrt(A^2 / (1 + X^2) + w2^2), a maximum iff A > 0).  w1, w2 enter by magnitude: the rectangle is symmetric.
+__device__ __forceinline__ float mf_max_dot(const MfCull &c, float wa, float w1, float w2, float wn)
+{
+    const bool inside = (wa > 0.0f) && (w1 <= c.X * wa) && (w2 <= c.Y * wa);
+    const float num = __builtin_fmaf(c.Y, w2, __builtin_fmaf(c.X, w1, wa));
+    const float corner = num * c.inv_len * (num > 0.0f ? 1.0003f : 1.0f);           // (inv_len is a lower bound of 1 / sqrt(1 + X^2 + Y^2))
+    const float A = __builtin_fmaf(c.X, w1, wa), B = __builtin_fmaf(c.X, c.X, 1.0f);
+    const float A2 = __builtin_fmaf(c.Y, w2, wa), B2 = __builtin_fmaf(c.Y, c.Y, 1.0f);
+    // (a stationary point behind the end of its edge: the function still rises at the corner, which has it)
+    const float e1 = (A > 0.0f && w2 * B <= c.Y * A) ? __builtin_amdgcn_sqrtf(__builtin_fmaf(A * A, __builtin_amdgcn_rcpf(B), w2 * w2)) : -__builtin_inff();
+    const float e2 = (A2 > 0.0f && w1 * B2 <= c.X * A2) ? __builtin_amdgcn_sqrtf(__builtin_fmaf(A2 * A2, __builtin_amdgcn_rcpf(B2), w1 * w1)) : -__builtin_inff();
+    const float m = fmaxf(corner, fmaxf(e1, e2));
+    return inside ? wn : fminf(m + 1e-4f * wn, wn);
+}
+
+__device__ __forceinline__ bool mf_certified(const MfCull &c, const MfPacket &p)
+{
+    const f3 g = p.O - mk(c.cx, c.cy, c.cz);                               // O - C
+    const float L = __builtin_amdgcn_sqrtf(dot3(g, g)) * 1.0001f;
+    const float nz = 9.5367431640625e-07f * __builtin_fmaf(c.E, p.On, c.Pw) * 1.01f;      // 2^-20 (E |o| + Pw): the reference's own rounding (mf_margin)
+    const f3 a = mk(c.ax, c.ay, c.az), t1 = mk(c.t1x, c.t1y, c.t1z), t2 = mk(c.t2x, c.t2y, c.t2z);
+    // ---- directions against the normals: lower bounds of d^.n^ (all back facing when > 0) and of -d^.n^ (all front facing when > 0)
+    const float Da = dot3(p.D, a), D1 = fabsf(dot3(p.D, t1)), D2 = fabsf(dot3(p.D, t2));
+    const float spread = __builtin_fmaf(c.X, D1, c.Y * D2);
+    const float num_pos = Da - spread, num_neg = -Da - spread;
+    const float lo_pos = (num_pos > 0.0f ? num_pos * c.inv_len : num_pos) - p.sigma - 1e-5f;
+    const float lo_neg = (num_neg > 0.0f ? num_neg * c.inv_len : num_neg) - p.sigma - 1e-5f;
+    const bool usable = c.Nmin > 0.0f;
+    // (K) every triangle back facing for every ray
+    const bool cert_k = (lo_pos > 0.0f) && ((c.Nmin * lo_pos) * 0.3333f * 0.99f >= nz);
+    // (A) the lines miss the tile's sphere by delta, and |d^.n^| >= cmin
+    const f3 W = cross3(p.D, g);                                          // moment of the axis about the tile's centre
+    const float Wn = __builtin_amdgcn_sqrtf(dot3(W, W));
+    const float delta = (Wn * 0.9999f - L * p.sigma) - (p.ro + c.R) - 1e-5f * (L + p.ro + c.R);
+    const float cmin = fmaxf(lo_pos, lo_neg);
+    const float lhs_a = (c.Nmin * cmin) * fminf(0.3333f, delta * c.shape) * 0.99f;
+    const bool cert_a = (delta > 0.0f) && (cmin > 0.0f) && (lhs_a > 0.0f) && (lhs_a >= nz);
+    // (B) the moment form
+    const float slack = (p.ro + c.Rc) + L * p.sigma + 1e-5f * (L + p.ro + c.Rc);
+    const float Wa = dot3(W, a), W1 = fabsf(dot3(W, t1)), W2 = fabsf(dot3(W, t2));
+    const float Wn_up = Wn * 1.0001f;
+    const float M = fmaxf(mf_max_dot(c, Wa, W1, W2, Wn_up), mf_max_dot(c, -Wa, W1, W2, Wn_up));
+    const float Wn_lo = Wn * 0.9999f;
+    const float wp = __builtin_amdgcn_sqrtf(fmaxf(0.0f, __builtin_fmaf(Wn_lo, Wn_lo, -(M * M)))) * 0.9999f - slack;
+    const float dist = Wn_lo - slack;
+    const float lhs_b = (c.hmin * wp) * (0.5f - (c.lmax * 0.33334f) * __builtin_amdgcn_rcpf(dist) * 1.0001f) * 0.99f;
+    const bool cert_b = (wp > 0.0f) && (dist > 1.3334f * c.lmax) && (M < Wn_lo) && (lhs_b > 0.0f) && (lhs_b >= nz);
+    return usable && (cert_k || cert_a || cert_b);                        // any NaN: false
 }
 
 }  // namespace rt

@@ -63,13 +63,13 @@ template <bool kMax> __device__ __forceinline__ float full_reduce(float x)
 }
 
 // ---- packet culling (rt_mfma.hpp, MfCull): for every granule of 128 consecutive rays of a queue (= the rays one scan wave handles
-// per trip) an origin sphere (O, ro), a direction cone (unit D, sigma = max |d^ - D|) and On >= max |o|, then the certificate against
-// every quad of the mesh: bit q of the granule's row of wb.keep is CLEAR when all 128 rays are certified rejections for all 40
-// triangles of quad q.  One wave per granule, two rays per lane for the bounds, one quad per lane for the test.  A granule with a
-// non-finite origin, a direction that cannot be normalised, or directions spread too widely to have an axis keeps every quad.
+// per trip) an origin sphere (O, ro), a direction cone (unit D, sigma = max |d^ - D|) and On >= max |o|, then the certificates against
+// every tile of the mesh: bit t of the granule's row of wb.keep is CLEAR when all 128 rays are certified rejections for all 10
+// triangles of tile t.  One wave per granule, two rays per lane for the bounds, one tile per lane for the test.  A granule with a
+// non-finite origin, a direction that cannot be normalised, or directions spread too widely to have an axis keeps every tile.
 // (Round 2 first evaluated the certificate inside the scan, per (wave, chunk) item: ~5,000 cycles per item for a scalar load of the
 // bounds, a conflict-ridden LDS read of the chunk's records and the test itself, 40 % of the camera-ray bounce.)
-__global__ void __launch_bounds__(256) packet_cull_kernel(WaveBuffers wb, const MfCull *__restrict__ cull, uint32_t n_quads, uint32_t bounce)
+__global__ void __launch_bounds__(256) packet_cull_kernel(WaveBuffers wb, const MfCull *__restrict__ cull, uint32_t n_tiles, uint32_t bounce)
 {
     const uint32_t n_rays = wb.counts[bounce];
     const RayQueue qin = (bounce & 1u) ? wb.q[1] : wb.q[0];
@@ -97,50 +97,37 @@ __global__ void __launch_bounds__(256) packet_cull_kernel(WaveBuffers wb, const 
         }
         olo = mk(full_reduce<false>(olo.x), full_reduce<false>(olo.y), full_reduce<false>(olo.z)); ohi = mk(full_reduce<true>(ohi.x), full_reduce<true>(ohi.y), full_reduce<true>(ohi.z));
         dlo = mk(full_reduce<false>(dlo.x), full_reduce<false>(dlo.y), full_reduce<false>(dlo.z)); dhi = mk(full_reduce<true>(dhi.x), full_reduce<true>(dhi.y), full_reduce<true>(dhi.z));
-        const f3 O = mk(0.5f * olo.x + 0.5f * ohi.x, 0.5f * olo.y + 0.5f * ohi.y, 0.5f * olo.z + 0.5f * ohi.z);
+        MfPacket pk;
+        pk.O = mk(0.5f * olo.x + 0.5f * ohi.x, 0.5f * olo.y + 0.5f * ohi.y, 0.5f * olo.z + 0.5f * ohi.z);
         f3 D = mk(0.5f * dlo.x + 0.5f * dhi.x, 0.5f * dlo.y + 0.5f * dhi.y, 0.5f * dlo.z + 0.5f * dhi.z);
         const float DD = dot3(D, D), iDl = __builtin_amdgcn_rsqf(DD), Dl = DD * iDl;
-        D = mk(D.x * iDl, D.y * iDl, D.z * iDl);                              // |D| = 1 +- 3e-7: covered by the slack of sigma
+        pk.D = mk(D.x * iDl, D.y * iDl, D.z * iDl);                           // |D| = 1 +- 3e-7: covered by the slack of sigma
         float ro = 0.0f, sigma = 0.0f;
 #pragma unroll
         for (int k = 0; k < 2; ++k)
             if (valid[k]) {
-                const f3 eo = o[k] - O, ed = dh[k] - D;
+                const f3 eo = o[k] - pk.O, ed = dh[k] - pk.D;
                 ro = fmaxf(ro, __builtin_amdgcn_sqrtf(dot3(eo, eo))); sigma = fmaxf(sigma, __builtin_amdgcn_sqrtf(dot3(ed, ed)));
             }
-        ro = full_reduce<true>(ro) * 1.0001f + 1e-30f; sigma = full_reduce<true>(sigma) * 1.0001f + 2e-6f;
+        pk.ro = full_reduce<true>(ro) * 1.0001f + 1e-30f; pk.sigma = full_reduce<true>(sigma) * 1.0001f + 2e-6f;
         usable = !__any(!usable) && (Dl > 0.25f);
-        const float On = __builtin_amdgcn_sqrtf(dot3(O, O)) * 1.0001f + ro;
+        pk.On = __builtin_amdgcn_sqrtf(dot3(pk.O, pk.O)) * 1.0001f + pk.ro;
         uint32_t *const row = wb.keep + (size_t)g * wb.keep_words;
         // (the record of the next pass travels while this one is evaluated)
         MfCull c_next = {};
-        bool have_next = usable && lane < n_quads;
+        bool have_next = usable && lane < n_tiles;
         if (have_next) c_next = cull[lane];
-        for (uint32_t q0 = 0; q0 < n_quads; q0 += 64u) {
+        for (uint32_t t0 = 0; t0 < n_tiles; t0 += 64u) {
             const MfCull c = c_next;
             const bool have_this = have_next;
-            have_next = usable && q0 + 64u + lane < n_quads;
-            if (have_next) c_next = cull[q0 + 64u + lane];
-            bool skip = false;
-            if (have_this) {
-                const f3 w = mk(c.cx, c.cy, c.cz) - O;
-                const float L = __builtin_amdgcn_sqrtf(dot3(w, w)) * 1.0001f;
-                const f3 cr = cross3(w, D);
-                const float crn = __builtin_amdgcn_sqrtf(dot3(cr, cr));
-                const float delta = (crn * 0.9999f - L * sigma) - (ro + c.R) - 1e-5f * (L + ro + c.R);      // the lines miss the sphere by at least this
-                // range of D.n^ over the box of the quad's unit normals; |d^.n^ - D.n^| <= sigma
-                const float plo = (fminf(D.x * c.nlx, D.x * c.nhx) + fminf(D.y * c.nly, D.y * c.nhy)) + fminf(D.z * c.nlz, D.z * c.nhz);
-                const float phi = (fmaxf(D.x * c.nlx, D.x * c.nhx) + fmaxf(D.y * c.nly, D.y * c.nhy)) + fmaxf(D.z * c.nlz, D.z * c.nhz);
-                const float cmin = ((plo > 0.0f) ? plo : ((phi < 0.0f) ? -phi : -1.0f)) - sigma - 1e-5f;
-                const float lhs = (c.Nmin * cmin) * fminf(0.3333f, delta * c.shape) * 0.99f;
-                const float rhs = 9.5367431640625e-07f * __builtin_fmaf(c.E, On, c.Pw) * 1.01f;      // 2^-20 (E |o| + Pw): the reference's own rounding (mf_margin)
-                skip = (delta > 0.0f) && (cmin > 0.0f) && (c.Nmin > 0.0f) && (lhs > 0.0f) && (lhs >= rhs);    // any NaN: false
-            }
-            const unsigned long long have = (n_quads - q0 >= 64u) ? ~0ull : ((1ull << (n_quads - q0)) - 1ull);
+            have_next = usable && t0 + 64u + lane < n_tiles;
+            if (have_next) c_next = cull[t0 + 64u + lane];
+            const bool skip = have_this && mf_certified(c, pk);
+            const unsigned long long have = (n_tiles - t0 >= 64u) ? ~0ull : ((1ull << (n_tiles - t0)) - 1ull);
             const unsigned long long keep = ~(unsigned long long)__builtin_amdgcn_ballot_w64(skip) & have;
             if (lane == 0u) {
-                store_through(row + (q0 >> 5), (uint32_t)keep);                     // (read by later kernels: rt_wavefront.hpp, store_through)
-                if ((q0 >> 5) + 1u < wb.keep_words) store_through(row + ((q0 >> 5) + 1u), (uint32_t)(keep >> 32));
+                store_through(row + (t0 >> 5), (uint32_t)keep);                     // (read by later kernels: rt_wavefront.hpp, store_through)
+                if ((t0 >> 5) + 1u < wb.keep_words) store_through(row + ((t0 >> 5) + 1u), (uint32_t)(keep >> 32));
             }
         }
     }
@@ -284,10 +271,54 @@ struct SoloCfg {
 #define RT_STAMP_ADD(acc, from, to)
 #endif
 
-// ---- culled bounces: the work items of a scan launch.  For every chunk of `chunk_quads` quads the granules whose keep bits are not all
-// clear, as (granule, keep bits of the chunk), compacted (one atomic per 64 granules; the order inside a chunk's list is whatever the
-// atomics made it: it only decides which wave scans what).  Granules with nothing to scan never become an item: with 95 % of the
-// camera rays' tests culled two thirds of the (granule, chunk) pairs of C2 are empty.  grid = (ceil(granules / 256), chunks).
+// ---- the keep bits of one (granule, chunk): up to 128 tiles = bits [tile_begin, tile_begin + n_tiles) of the granule's row, as a
+// 128-bit mask (wave-uniform in the scan: scalar loads and scalar arithmetic).  The words behind the end of a row belong to the next
+// rows (the buffer ends 16 rows behind the last granule): masked out.
+struct Mask128 { unsigned long long lo, hi; };
+__device__ __forceinline__ Mask128 m128_shr(Mask128 m, uint32_t s)
+{
+    Mask128 r;
+    if (s >= 128u) { r.lo = 0ull; r.hi = 0ull; }
+    else if (s >= 64u) { r.lo = m.hi >> (s - 64u); r.hi = 0ull; }
+    else if (s == 0u) r = m;
+    else { r.lo = (m.lo >> s) | (m.hi << (64u - s)); r.hi = m.hi >> s; }
+    return r;
+}
+__device__ __forceinline__ Mask128 m128_low(uint32_t n)                 // the n lowest bits set, n <= 128
+{
+    Mask128 r;
+    r.lo = n >= 64u ? ~0ull : ((1ull << n) - 1ull);
+    r.hi = n >= 128u ? ~0ull : (n > 64u ? ((1ull << (n - 64u)) - 1ull) : 0ull);
+    return r;
+}
+__device__ __forceinline__ Mask128 m128_and(Mask128 a, Mask128 b) { Mask128 r; r.lo = a.lo & b.lo; r.hi = a.hi & b.hi; return r; }
+__device__ __forceinline__ bool m128_any(Mask128 m) { return (m.lo | m.hi) != 0ull; }
+__device__ __forceinline__ uint32_t m128_popc(Mask128 m) { return (uint32_t)__builtin_popcountll(m.lo) + (uint32_t)__builtin_popcountll(m.hi); }
+__device__ __forceinline__ uint32_t m128_ctz(Mask128 m)                 // index of the lowest set bit; 128: none
+{
+    return m.lo ? (uint32_t)__builtin_ctzll(m.lo) : (m.hi ? 64u + (uint32_t)__builtin_ctzll(m.hi) : 128u);
+}
+__device__ __forceinline__ uint32_t m128_cto(Mask128 m)                 // number of consecutive set bits from bit 0
+{
+    Mask128 n; n.lo = ~m.lo; n.hi = ~m.hi;
+    return m128_ctz(n);
+}
+template <typename Words>
+__device__ __forceinline__ Mask128 chunk_keep_bits(Words row, uint32_t tile_begin, uint32_t n_tiles)
+{
+    const Words w = row + (tile_begin >> 5);
+    const uint32_t sh = tile_begin & 31u;
+    const unsigned long long w01 = (unsigned long long)w[0] | ((unsigned long long)w[1] << 32), w23 = (unsigned long long)w[2] | ((unsigned long long)w[3] << 32), w4 = w[4];
+    Mask128 m;
+    m.lo = sh ? (w01 >> sh) | (w23 << (64u - sh)) : w01;
+    m.hi = sh ? (w23 >> sh) | (w4 << (64u - sh)) : w23;
+    return m128_and(m, m128_low(n_tiles));
+}
+
+// ---- culled bounces: the work items of a dynamic scan launch.  For every chunk of `chunk_quads` quads the granules whose keep bits are
+// not all clear, compacted (one atomic per 64 granules; the order inside a chunk's list is whatever the atomics made it: it only
+// decides which wave scans what).  Granules with nothing to scan never become an item: with 95 % of the camera rays' tests culled
+// two thirds of the (granule, chunk) pairs of C2 are empty.  grid = (ceil(granules / 256), chunks).
 template <bool kCount>
 __global__ void __launch_bounds__(256) cull_items_kernel(WaveBuffers wb, uint32_t bounce, uint32_t chunk_quads, uint32_t n_quads, Counters *__restrict__ counters)
 {
@@ -295,22 +326,22 @@ __global__ void __launch_bounds__(256) cull_items_kernel(WaveBuffers wb, uint32_
     const uint32_t c = blockIdx.y, q_begin = c * chunk_quads, q_end = min(q_begin + chunk_quads, n_quads);
     const uint32_t lane = threadIdx.x & 63u;
     if (q_begin >= q_end) return;
+    const uint32_t n_tiles = (q_end - q_begin) * kMfQuadTiles;
     unsigned long long culled = 0;
     for (uint32_t g0 = blockIdx.x * 256u + (threadIdx.x & ~63u); g0 < n_gran; g0 += gridDim.x * 256u) {      // (wave-uniform bound)
         const uint32_t g = g0 + lane;
-        uint32_t bits = 0u;
+        bool any = false;
         if (g < n_gran) {
-            const uint32_t *w = wb.keep + ((size_t)g * wb.keep_words + (q_begin >> 5));
-            const unsigned long long two = (unsigned long long)w[0] | ((unsigned long long)w[1] << 32);    // (the second word may lie behind the row: masked out)
-            bits = (uint32_t)(two >> (q_begin & 31u)) & (0xFFFFFFFFu >> (32u - (q_end - q_begin)));
-            if (kCount) culled += (unsigned long long)((q_end - q_begin) - (uint32_t)__popc(bits)) * kMfQuadTris * min(128u, n_rays - g * 128u);
+            const Mask128 bits = chunk_keep_bits(wb.keep + (size_t)g * wb.keep_words, q_begin * kMfQuadTiles, n_tiles);
+            any = m128_any(bits);
+            if (kCount) culled += (unsigned long long)(n_tiles - m128_popc(bits)) * kMfTileTris * min(128u, n_rays - g * 128u);
         }
-        const unsigned long long m = __builtin_amdgcn_ballot_w64(bits != 0u);
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(any);
         if (m == 0ull) continue;
         uint32_t at = 0u;
         if (lane == 0u) at = atomicAdd(wb.item_counts + c, (uint32_t)__popcll(m));
         at = __builtin_amdgcn_readfirstlane(at) + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-        if (bits != 0u) store_through(reinterpret_cast<unsigned long long *>(wb.items + ((size_t)c * wb.items_stride + at)), (unsigned long long)g | ((unsigned long long)bits << 32));
+        if (any) store_through(wb.items + ((size_t)c * wb.items_stride + at), g);
     }
     if (kCount && culled) atomicAdd(&counters->culled_tests, culled);
 }
@@ -431,8 +462,8 @@ scan_solo_kernel(SceneView sc, WaveBuffers wb, MfView mf, uint32_t bounce, uint3
         c_from = (c + 1u) % n_chunks;
         const uint32_t q_begin = c * chunk_quads, q_end = min(q_begin + chunk_quads, real_quads);
         const uint32_t v_chunk_begin = q_begin * kMfQuadTris, v_chunk_end = min(q_end * (uint32_t)kMfQuadTris, sc.n_tri_visits);
-        const uint32_t n_tiles = (q_end - q_begin) * kMfQuadTiles;
-        const uint32_t keep_all = 0xFFFFFFFFu >> (32u - (q_end - q_begin));
+        const uint32_t n_tiles = (q_end - q_begin) * kMfQuadTiles, tile_begin = q_begin * kMfQuadTiles;
+        const Mask128 keep_all = m128_low(n_tiles);
         {
             const uint32_t n16 = (q_end - q_begin) * (kQuadBytes / 16u);
             const uint4 *src = mf.A + (size_t)q_begin * (kQuadBytes / 16u);
@@ -474,39 +505,36 @@ scan_solo_kernel(SceneView sc, WaveBuffers wb, MfView mf, uint32_t bounce, uint3
             const uint32_t at = __builtin_amdgcn_readfirstlane(v);
             lo = min(at, n_items); end = min(at + n, n_items);
         };
-        // item k of the chunk: the granule and which of the chunk's quads its rays cannot be rejected for (bit q: quad q must be scanned).
-        // Culled bounces: dynamic launches read the compacted list of cull_items_kernel, static ones the granule's own keep bits (the
-        // chunk's <= 32 bits sit in at most two words of the row; the second may lie behind the row: masked out, the buffer ends 16
-        // rows behind the last granule), through the scalar cache.
+        // item k of the chunk: the granule and which of the chunk's tiles its rays cannot be rejected for (bit t: tile t must be
+        // scanned).  Culled bounces: dynamic launches take the granule from the compacted list of cull_items_kernel; the keep bits come
+        // from the granule's row (chunk_keep_bits), through the scalar cache.
         const ConstWords keep_k = (ConstWords)(uintptr_t)wb.keep;
-        auto item_of = [&](uint32_t k, uint32_t &g, uint32_t &bits) {
+        auto item_of = [&](uint32_t k, uint32_t &g, Mask128 &bits) {
             g = k; bits = keep_all;
             if (cull) {
-                if (dynamic) { g = items_k[2u * (size_t)k]; bits = items_k[2u * (size_t)k + 1u]; }
-                else {
-                    const ConstWords w = keep_k + ((size_t)k * wb.keep_words + (q_begin >> 5));
-                    bits = (uint32_t)(((unsigned long long)w[0] | ((unsigned long long)w[1] << 32)) >> (q_begin & 31u)) & keep_all;
-                }
+                if (dynamic) g = items_k[k];
+                bits = chunk_keep_bits(keep_k + (size_t)g * wb.keep_words, tile_begin, n_tiles);
             }
         };
         uint32_t k, hi, step;
         if (dynamic) { step = 1u; claim(0u, k, hi); }
         else { step = blocks_here * kWaves; k = rank_here * kWaves + (uint32_t)wave; hi = n_items; }
-        uint32_t rec_k = kNone, rec_g = 0u, rec_keep = 0u;     // the record of an item read ahead
+        uint32_t rec_k = kNone, rec_g = 0u;                    // the record of an item read ahead
+        Mask128 rec_keep = {0ull, 0ull};
         uint32_t ray_k = kNone;                                // W = 1: the item whose rays are in (or on their way to) nxt_a / nxt_b
         auto advance = [&]() { k += step; if (dynamic && k >= hi) claim(hi, k, hi); };      // (dynamic: the batch is used up)
         while (k < hi) {
             RT_STAMP(ts_iter);
-            uint32_t g, keep;
+            uint32_t g; Mask128 keep;
             if (rec_k == k) { g = rec_g; keep = rec_keep; } else item_of(k, g, keep);
             const uint32_t wave_slot0 = g * 128u;
             // the item after this one, if it is known already: its record (and with one wave per SIMD its rays) travel during the scan
             const uint32_t succ = k + step < hi ? k + step : kNone;
             if (succ != kNone) { item_of(succ, rec_g, rec_keep); rec_k = succ; }
             if (kCount && cull && !dynamic && lane == 0)          // (dynamic launches count these in cull_items_kernel)
-                c_culled += (unsigned long long)__builtin_popcount(~keep & keep_all) * kMfQuadTris * min(128u, n_rays - wave_slot0);
-            if (keep == 0u) {                                  // (static, culled bounce) nothing of this chunk can be hit by this granule's rays
-                if constexpr (W == 1) { if (succ != kNone && rec_keep != 0u) { fetch_rays(rec_g, nxt_a, nxt_b); ray_k = succ; } }
+                c_culled += (unsigned long long)(n_tiles - m128_popc(keep)) * kMfTileTris * min(128u, n_rays - wave_slot0);
+            if (!m128_any(keep)) {                             // (static, culled bounce) nothing of this chunk can be hit by this granule's rays
+                if constexpr (W == 1) { if (succ != kNone && m128_any(rec_keep)) { fetch_rays(rec_g, nxt_a, nxt_b); ray_k = succ; } }
                 advance();
                 continue;
             }
@@ -516,162 +544,167 @@ scan_solo_kernel(SceneView sc, WaveBuffers wb, MfView mf, uint32_t bounce, uint3
 #pragma unroll
                 for (int s = 0; s < S; ++s) prepare_ray(ray[s], nxt_a[s], nxt_b[s], wave_slot0 + (uint32_t)s * 32u + (uint32_t)col < n_rays);
                 // the next item's rays travel while this one is scanned (one wave per SIMD: nothing else would hide the round trip)
-                if (succ != kNone && rec_keep != 0u) { fetch_rays(rec_g, nxt_a, nxt_b); ray_k = succ; }
+                if (succ != kNone && m128_any(rec_keep)) { fetch_rays(rec_g, nxt_a, nxt_b); ray_k = succ; }
             }
 
-        uint32_t qn = 0;                                        // wave-uniform
-        auto flush = [&]() {
-            // Every (queue entry, ray set) with a non-empty 5-bit mask becomes one record (queue slot of the ray, storage position of the
-            // lane's first triangle << 5 | mask), appended densely to the wave's region (ballot + prefix count per ray set), fire and
-            // forget; the narrow phase expands the masks and maps storage position -> visit index.  What does not fit gets its exact
-            // tests right here, so the result never depends on the buffer size.  `appended` is 64 bits wide: a degenerate scene (NaN
-            // bounds: every pair survives) can exceed 2^32 records per wave.
-            for (uint32_t i0 = 0; i0 < qn; i0 += 64u) {
-                const uint32_t i = i0 + (uint32_t)lane;
-                const uint2 e = i < qn ? queue[i] : make_uint2(0u, 0u);
-                const uint32_t ln = e.x & 63u, pos5 = v_chunk_begin + (e.x >> 8) * kMfTileTris + 5u * (ln >> 5);
-                if (kCount) c_cand_lane += (unsigned long long)__popc(e.y);
-                const uint32_t bits = debug_skip_exact == 0 ? e.y : 0u;
+            uint32_t qn = 0;                                    // wave-uniform
+            auto flush = [&]() {
+                // Every (queue entry, ray set) with a non-empty 5-bit mask becomes one record (queue slot of the ray, storage position of
+                // the lane's first triangle << 5 | mask), appended densely to the wave's region (ballot + prefix count per ray set), fire
+                // and forget; the narrow phase expands the masks and maps storage position -> visit index.  What does not fit gets its
+                // exact tests right here, so the result never depends on the buffer size.  `appended` is 64 bits wide: a degenerate
+                // scene (NaN bounds: every pair survives) can exceed 2^32 records per wave.
+                for (uint32_t i0 = 0; i0 < qn; i0 += 64u) {
+                    const uint32_t i = i0 + (uint32_t)lane;
+                    const uint2 e = i < qn ? queue[i] : make_uint2(0u, 0u);
+                    const uint32_t ln = e.x & 63u, pos5 = v_chunk_begin + (e.x >> 8) * kMfTileTris + 5u * (ln >> 5);
+                    if (kCount) c_cand_lane += (unsigned long long)__popc(e.y);
+                    const uint32_t bits = debug_skip_exact == 0 ? e.y : 0u;
+#pragma unroll
+                    for (int s = 0; s < S; ++s) {
+                        uint32_t um = (bits >> (5 * s)) & 31u;
+                        const unsigned long long m = __builtin_amdgcn_ballot_w64(um != 0u);
+                        const unsigned long long at = appended + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                        const uint32_t slot = wave_slot0 + (uint32_t)(s * 32) + (ln & 31u);
+                        if (um != 0u) {
+                            if (at < (unsigned long long)wb.cand_region) store_through(reinterpret_cast<unsigned long long *>(cand + at), (unsigned long long)slot | ((unsigned long long)((pos5 << 5) | um) << 32));
+                            else
+                                while (um) {
+                                    const uint32_t pos = pos5 + (uint32_t)__builtin_ctz(um);
+                                    um &= um - 1u;
+                                    if (pos < v_chunk_end) exact_and_merge_at(mf, qin, best, slot, pos);
+                                }
+                        }
+                        appended += (unsigned long long)__popcll(m);
+                    }
+                }
+                qn = 0;
+            };
+
+            u32x4 B0, B1, B2, B3;                               // B operands (K layout: see MfView) and thresholds of the four ray sets
+            float th0, th1, th2, th3;
+            f32x16 X0, X1, X2, X3, Y0, Y1, Y2, Y3;
+            f32x6 MA0, MA1, MA2, MA3, MB0, MB1, MB2, MB3;        // [0..4]: minima of the five triangles of the lane's half, [5]: their maximum
+            unsigned long long any_a, any_b;                    // lanes with a survivor in the tile examined into MA / MB
+            // rare path: some lane has a survivor in `tile` (index inside the chunk).  Branch-free: every lane builds the 20-bit mask of
+            // its surviving (ray set, triangle) pairs from the minima the stage left behind, lanes with a non-empty mask append ONE
+            // entry to the wave's LDS queue (the others write to a scratch entry).  (The first form of this path tested set by set and
+            // triangle by triangle with a scalar branch each: ~40 cycles per branch, 350-400 per parking event, 17 % of a bounce.)  A
+            // finite threshold means finite operands and edge values below 2^7 * 1e30 in magnitude, hence finite minima; a NaN
+            // threshold passes all.
+            auto append = [&](uint32_t tile, uint32_t mask) {
+                const unsigned long long m = __builtin_amdgcn_ballot_w64(mask != 0u);
+                uint32_t pre = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                asm volatile("" : "+v"(pre));                   // (keeps the prefix count out of a branch on "any lane active")
+                queue[mask ? qn + pre : Cfg::kQueue - 1u] = make_uint2((uint32_t)lane | (tile << 8), mask);
+                qn += (uint32_t)__popcll(m);
+                if (qn >= Cfg::kDrain) flush();
+            };
+            auto park_a = [&](uint32_t tile) { RT_STAMP(ts_p0); uint32_t mask; RT_MASK_A(mask); append(tile, mask); RT_STAMP(ts_p1); RT_STAMP_ADD(tt_park, ts_p0, ts_p1); };
+            auto park_b = [&](uint32_t tile) { RT_STAMP(ts_p0); uint32_t mask; RT_MASK_B(mask); append(tile, mask); RT_STAMP(ts_p1); RT_STAMP_ADD(tt_park, ts_p0, ts_p1); };
+            RT_STAMP(ts_rays);
+            RT_STAMP_ADD(tt_rays, ts_iter, ts_rays);
+
+            // segments = runs of tiles that share one group (local origin + bounds); a chunk may start or end inside a group
+            for (uint32_t ts0 = 0; ts0 < n_tiles;) {
+                RT_STAMP(ts_g0);
+                const uint32_t q = q_begin + ts0 / kMfQuadTiles;
+                const uint32_t grp = q >> group_shift;
+                const uint32_t ts1 = min(n_tiles, (((grp + 1u) << group_shift) - q_begin) * kMfQuadTiles);
+                // tiles of this segment the wave still has to scan (bit i: tile ts0 + i); a segment that is culled altogether costs
+                // nothing, not even its setup
+                Mask128 seg = m128_and(m128_shr(keep, ts0), m128_low(ts1 - ts0));
+                if (!m128_any(seg)) { ts0 = ts1; continue; }
+                if constexpr (W == 2) {                          // nothing ray-related stays live across the tile loop: re-read the queue here
+                    fetch_rays(g, nxt_a, nxt_b);
+#pragma unroll
+                    for (int s = 0; s < S; ++s) prepare_ray(ray[s], nxt_a[s], nxt_b[s], wave_slot0 + (uint32_t)s * 32u + (uint32_t)col < n_rays);
+                }
+                const ConstFloats gp = groups_k + (size_t)grp * (sizeof(MfGroup) / 4);
+                MfGroup G;
+                G.cx = gp[0]; G.cy = gp[1]; G.cz = gp[2]; G.E = gp[3]; G.Ml = gp[4]; G.Pw = gp[5]; G.P = gp[6]; G.pad1 = 0.0f;
+                u32x4 Bs[S]; float ths[S];
 #pragma unroll
                 for (int s = 0; s < S; ++s) {
-                    uint32_t um = (bits >> (5 * s)) & 31u;
-                    const unsigned long long m = __builtin_amdgcn_ballot_w64(um != 0u);
-                    const unsigned long long at = appended + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                    const uint32_t slot = wave_slot0 + (uint32_t)(s * 32) + (ln & 31u);
-                    if (um != 0u) {
-                        if (at < (unsigned long long)wb.cand_region) store_through(reinterpret_cast<unsigned long long *>(cand + at), (unsigned long long)slot | ((unsigned long long)((pos5 << 5) | um) << 32));
-                        else
-                            while (um) {
-                                const uint32_t pos = pos5 + (uint32_t)__builtin_ctz(um);
-                                um &= um - 1u;
-                                if (pos < v_chunk_end) exact_and_merge_at(mf, qin, best, slot, pos);
-                            }
+                    const MfRay &r = ray[s];
+                    const f3 ol = r.o - mk(G.cx, G.cy, G.cz);
+                    const f3 cvl = cross3(r.d, ol);
+                    // v_sqrt_f32 (1 ulp) instead of the correctly rounded sequence: these are bounds, inflated by 1.001
+                    const float ncv = __builtin_amdgcn_sqrtf(dot3(cvl, cvl)) * 1.001f, no = __builtin_amdgcn_sqrtf(dot3(ol, ol)) * 1.001f;
+                    const float margin = mf_margin(G, ncv, no, r);
+                    // empty slot: nothing survives.  Margin not finite or so large that the bf16 products could overflow (bounds NaN for
+                    // non-finite vertices, huge coordinates): NaN threshold, everything survives.
+                    ths[s] = (!r.valid || debug_skip_exact == 2) ? __builtin_inff() : (margin < 1.0e30f ? -margin : __builtin_nanf(""));
+                    Bs[s].x = pack_bf16(cvl.x, cvl.y);
+                    Bs[s].y = (pack_bf16(cvl.z, 0.0f) & 0xffffu) | r.dx_hi;
+                    Bs[s].z = r.dyz; Bs[s].w = r.tail;
+                }
+                B0 = Bs[0]; B1 = Bs[1]; B2 = Bs[2]; B3 = Bs[3];
+                th0 = ths[0]; th1 = ths[1]; th2 = ths[2]; th3 = ths[3];
+                uint32_t run_at = ts0;                          // tile of bit 0 of `seg`
+                while (m128_any(seg)) {
+                    // next run of consecutive tiles to scan: [t0, t1)
+                    const uint32_t skip = m128_ctz(seg);
+                    seg = m128_shr(seg, skip);
+                    const uint32_t run = m128_cto(seg);
+                    seg = m128_shr(seg, run);
+                    const uint32_t t0 = run_at + skip, t1 = t0 + run;
+                    run_at = t1;
+                    // prologue: the products of the run's first tile.  The tile rows of a trip are read two trips ahead (by the trip
+                    // statement itself); the four rows behind the chunk's last tile are allocated (and never used).
+                    const uint4 *row = lds_tiles + (size_t)t0 * 64u + l_lane;
+                    auto tile_row = [&]() { const uint4 r = *row; row += 64; return u32x4{r.x, r.y, r.z, r.w}; };
+                    u32x4 ap = tile_row(), ay = tile_row(), ax = tile_row(), by, bx;
+                    typedef const uint4 __attribute__((address_space(3))) *LdsRow;
+                    uint32_t addr = (uint32_t)(uintptr_t)(LdsRow)row;                       // LDS byte address of tile t0 + 3's row
+                    RT_PRODUCTS_X(ap);
+                    // steady state: two stages per trip (tile t -> Y beside the examination of tile t-1, tile t+1 -> X beside the
+                    // examination of tile t), so that X and Y swap roles without moves; two trips per loop iteration, so that the tile
+                    // rows do, too
+                    uint32_t t = t0 + 1u;
+                    for (; t + 3u < t1; t += 4u) {
+                        RT_TRIP_L(ay, ax, by, bx, addr);
+                        if (__builtin_expect((any_a | any_b) != 0ull, 0)) {
+                            if (any_a) park_a(t - 1u);
+                            if (any_b) park_b(t);
+                        }
+                        RT_TRIP_L(by, bx, ay, ax, addr);
+                        if (__builtin_expect((any_a | any_b) != 0ull, 0)) {
+                            if (any_a) park_a(t + 1u);
+                            if (any_b) park_b(t + 2u);
+                        }
                     }
-                    appended += (unsigned long long)__popcll(m);
+                    if (t + 1u < t1) {                                                       // two or three tiles left: one more trip
+                        RT_TRIP_L(ay, ax, by, bx, addr);
+                        if ((any_a | any_b) != 0ull) {
+                            if (any_a) park_a(t - 1u);
+                            if (any_b) park_b(t);
+                        }
+                        ay = by; t += 2u;
+                    }
+                    // epilogue: a last single stage if the run's tile count is even, then the examination of the last tile (park()
+                    // finds nothing when there is nothing)
+                    if (t < t1) {
+                        RT_STAGE_Y(ay);
+                        if (any_a) park_a(t - 1u);
+                        RT_EXAMINE_Y();
+                        park_b(t);
+                    } else {
+                        RT_EXAMINE_X();
+                        park_a(t - 1u);
+                    }
                 }
+                ts0 = ts1;
+                RT_STAMP(ts_g2);
+                RT_STAMP_ADD(tt_steady, ts_g0, ts_g2);
             }
-            qn = 0;
-        };
-
-        u32x4 B0, B1, B2, B3;                                   // B operands (K layout: see MfView) and thresholds of the four ray sets
-        float th0, th1, th2, th3;
-        f32x16 X0, X1, X2, X3, Y0, Y1, Y2, Y3;
-        f32x6 MA0, MA1, MA2, MA3, MB0, MB1, MB2, MB3;            // [0..4]: minima of the five triangles of the lane's half, [5]: their maximum
-        unsigned long long any_a, any_b;                        // lanes with a survivor in the tile examined into MA / MB
-        // rare path: some lane has a survivor in `tile` (index inside the chunk).  Branch-free: every lane builds the 20-bit mask of
-        // its surviving (ray set, triangle) pairs from the minima the stage left behind, lanes with a non-empty mask append ONE entry
-        // to the wave's LDS queue (the others write to a scratch entry).  (The first form of this path tested set by set and triangle
-        // by triangle with a scalar branch each: ~40 cycles per branch, 350-400 per parking event, 17 % of a bounce.)  A finite
-        // threshold means finite operands and edge values below 2^7 * 1e30 in magnitude, hence finite minima; a NaN threshold passes all.
-        auto append = [&](uint32_t tile, uint32_t mask) {
-            const unsigned long long m = __builtin_amdgcn_ballot_w64(mask != 0u);
-            uint32_t pre = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-            asm volatile("" : "+v"(pre));                       // (keeps the prefix count out of a branch on "any lane active")
-            queue[mask ? qn + pre : Cfg::kQueue - 1u] = make_uint2((uint32_t)lane | (tile << 8), mask);
-            qn += (uint32_t)__popcll(m);
-            if (qn >= Cfg::kDrain) flush();
-        };
-        auto park_a = [&](uint32_t tile) { RT_STAMP(ts_p0); uint32_t mask; RT_MASK_A(mask); append(tile, mask); RT_STAMP(ts_p1); RT_STAMP_ADD(tt_park, ts_p0, ts_p1); };
-        auto park_b = [&](uint32_t tile) { RT_STAMP(ts_p0); uint32_t mask; RT_MASK_B(mask); append(tile, mask); RT_STAMP(ts_p1); RT_STAMP_ADD(tt_park, ts_p0, ts_p1); };
-        RT_STAMP(ts_rays);
-        RT_STAMP_ADD(tt_rays, ts_iter, ts_rays);
-
-        // segments = runs of tiles that share one group (local origin + bounds); a chunk may start or end inside a group
-        for (uint32_t ts0 = 0; ts0 < n_tiles;) {
-            RT_STAMP(ts_g0);
-            const uint32_t q = q_begin + ts0 / kMfQuadTiles;
-            const uint32_t grp = q >> group_shift;
-            const uint32_t ts1 = min(n_tiles, (((grp + 1u) << group_shift) - q_begin) * kMfQuadTiles);
-            // quads of this segment the wave still has to scan; a segment that is culled altogether costs nothing, not even its setup
-            const uint32_t qa = ts0 / kMfQuadTiles, nq = (ts1 - ts0) / kMfQuadTiles;
-            uint32_t seg = keep & ((nq >= 32u ? 0xFFFFFFFFu : ((1u << nq) - 1u)) << qa);
-            if (seg == 0u) { ts0 = ts1; continue; }
-            if constexpr (W == 2) {                              // nothing ray-related stays live across the tile loop: re-read the queue here
-                fetch_rays(g, nxt_a, nxt_b);
-#pragma unroll
-                for (int s = 0; s < S; ++s) prepare_ray(ray[s], nxt_a[s], nxt_b[s], wave_slot0 + (uint32_t)s * 32u + (uint32_t)col < n_rays);
-            }
-            const ConstFloats gp = groups_k + (size_t)grp * (sizeof(MfGroup) / 4);
-            MfGroup G;
-            G.cx = gp[0]; G.cy = gp[1]; G.cz = gp[2]; G.E = gp[3]; G.Ml = gp[4]; G.Pw = gp[5]; G.P = gp[6]; G.pad1 = 0.0f;
-            u32x4 Bs[S]; float ths[S];
-#pragma unroll
-            for (int s = 0; s < S; ++s) {
-                const MfRay &r = ray[s];
-                const f3 ol = r.o - mk(G.cx, G.cy, G.cz);
-                const f3 cvl = cross3(r.d, ol);
-                // v_sqrt_f32 (1 ulp) instead of the correctly rounded sequence: these are bounds, inflated by 1.001
-                const float ncv = __builtin_amdgcn_sqrtf(dot3(cvl, cvl)) * 1.001f, no = __builtin_amdgcn_sqrtf(dot3(ol, ol)) * 1.001f;
-                const float margin = mf_margin(G, ncv, no, r);
-                // empty slot: nothing survives.  Margin not finite or so large that the bf16 products could overflow (bounds NaN for
-                // non-finite vertices, huge coordinates): NaN threshold, everything survives.
-                ths[s] = (!r.valid || debug_skip_exact == 2) ? __builtin_inff() : (margin < 1.0e30f ? -margin : __builtin_nanf(""));
-                Bs[s].x = pack_bf16(cvl.x, cvl.y);
-                Bs[s].y = (pack_bf16(cvl.z, 0.0f) & 0xffffu) | r.dx_hi;
-                Bs[s].z = r.dyz; Bs[s].w = r.tail;
-            }
-            B0 = Bs[0]; B1 = Bs[1]; B2 = Bs[2]; B3 = Bs[3];
-            th0 = ths[0]; th1 = ths[1]; th2 = ths[2]; th3 = ths[3];
-            while (seg != 0u) {
-            // next run of consecutive quads to scan: tiles [t0, t1)
-            const uint32_t qs = (uint32_t)__builtin_ctz(seg), inv = ~(seg >> qs);
-            const uint32_t run = inv ? (uint32_t)__builtin_ctz(inv) : 32u - qs;
-            seg &= ~((run >= 32u ? 0xFFFFFFFFu : ((1u << run) - 1u)) << qs);
-            const uint32_t t0 = qs * kMfQuadTiles, t1 = (qs + run) * kMfQuadTiles;
-            // prologue: the products of the segment's first tile.  The tile rows of a trip are read two trips ahead (by the trip
-            // statement itself); the four rows behind the chunk's last tile are allocated (and never used).
-            const uint4 *row = lds_tiles + (size_t)t0 * 64u + l_lane;
-            auto tile_row = [&]() { const uint4 r = *row; row += 64; return u32x4{r.x, r.y, r.z, r.w}; };
-            u32x4 ap = tile_row(), ay = tile_row(), ax = tile_row(), by, bx;
-            typedef const uint4 __attribute__((address_space(3))) *LdsRow;
-            uint32_t addr = (uint32_t)(uintptr_t)(LdsRow)row;                           // LDS byte address of tile t0 + 3's row
-            RT_PRODUCTS_X(ap);
-            // steady state: two stages per trip (tile t -> Y beside the examination of tile t-1, tile t+1 -> X beside the examination
-            // of tile t), so that X and Y swap roles without moves; two trips per loop iteration, so that the tile rows do, too
-            uint32_t t = t0 + 1u;
-            for (; t + 3u < t1; t += 4u) {
-                RT_TRIP_L(ay, ax, by, bx, addr);
-                if (__builtin_expect((any_a | any_b) != 0ull, 0)) {
-                    if (any_a) park_a(t - 1u);
-                    if (any_b) park_b(t);
-                }
-                RT_TRIP_L(by, bx, ay, ax, addr);
-                if (__builtin_expect((any_a | any_b) != 0ull, 0)) {
-                    if (any_a) park_a(t + 1u);
-                    if (any_b) park_b(t + 2u);
-                }
-            }
-            if (t + 1u < t1) {                                                           // two or three tiles left: one more trip
-                RT_TRIP_L(ay, ax, by, bx, addr);
-                if ((any_a | any_b) != 0ull) {
-                    if (any_a) park_a(t - 1u);
-                    if (any_b) park_b(t);
-                }
-                ay = by; t += 2u;
-            }
-            // epilogue: a last single stage if the segment's tile count is even, then the examination of the last tile (park() finds
-            // nothing when there is nothing)
-            if (t < t1) {
-                RT_STAGE_Y(ay);
-                if (any_a) park_a(t - 1u);
-                RT_EXAMINE_Y();
-                park_b(t);
-            } else {
-                RT_EXAMINE_X();
-                park_a(t - 1u);
-            }
-            }
-            ts0 = ts1;
-            RT_STAMP(ts_g2);
-            RT_STAMP_ADD(tt_steady, ts_g0, ts_g2);
-        }
-        RT_STAMP(ts_f0);
-        flush();
+            RT_STAMP(ts_f0);
+            flush();
             advance();
-        RT_STAMP(ts_f1);
-        RT_STAMP_ADD(tt_flush, ts_f0, ts_f1);
+            RT_STAMP(ts_f1);
+            RT_STAMP_ADD(tt_flush, ts_f0, ts_f1);
 #ifdef RT_SOLO_STAMPS
-        tt_iters++; tt_tiles += n_tiles;
+            tt_iters++; tt_tiles += n_tiles;
 #endif
         }
         if (!dynamic) break;                                   // static: a block stays with the chunk it started on

@@ -48,9 +48,9 @@ struct WaveBuffers {
                                   // one region of `cand_region` pairs per wave of the scan launch
     uint32_t *cand_counts;        // kernel 4: pairs stored in each region by the scan launch of the current bounce
     uint32_t cand_region;         // capacity of one region (pairs); what does not fit is tested in place by the scan
-    uint32_t *keep;               // kernel 4 packet culling: per granule of 128 rays of the queue being scanned, one bit per quad (rt_scan.hpp, packet_cull_kernel)
-    uint32_t keep_words;          // 32-bit words per granule = ceil(quads / 32)
-    uint2 *items;                 // kernel 4, culled bounces: per chunk of the scan launch the granules that have anything to scan, (granule, keep bits)
+    uint32_t *keep;               // kernel 4 packet culling: per granule of 128 rays of the queue being scanned, one bit per tile of 10 triangles (rt_scan.hpp, packet_cull_kernel)
+    uint32_t keep_words;          // 32-bit words per granule = ceil(tiles / 32)
+    uint32_t *items;              // kernel 4, culled dynamic launches: per chunk of the scan launch the granules that have anything to scan
     uint32_t *item_counts;        //   ... their number per chunk; items_stride entries are reserved per chunk (cull_items_kernel)
     uint32_t items_stride;
     uint32_t *sched;              // kernel 4: per scan launch (bounce) and chunk the next unclaimed item; zeroed with the ray counts at frame start

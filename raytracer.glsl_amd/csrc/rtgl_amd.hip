@@ -610,39 +610,46 @@ static int rebuild_sphere_visits(rtgl_context *ctx)
     return RTGL_OK;
 }
 
-// Storage order of the triangle visits for the matrix-core broad phase: sorted by the Morton code of the triangle
-// centroid (10 bits per axis, ONE scale for all three axes: cells must be cubes in world space or a height field gets cut
-// into contour strips), ties by visit index.  Only tightness of the
-// per-group bounds depends on it; non-finite centroids simply land in cell 0.
-static std::vector<uint32_t> morton_order(const rtgl_context *ctx, const std::vector<uint32_t> &visit_tri)
+// Storage order of the triangle visits for the matrix-core broad phase: the leaves of a k-d tree over the triangle centroids (median
+// split along the longest axis of the centroid box), written out left to right.  A leaf is one MFMA tile (10 triangles); the split
+// positions are multiples of the unit above them (tile -> quad of 4 tiles -> group of `group_tris` triangles), so every tile, quad and
+// group of the storage order is one subtree: spatially compact at every level (a bumpy height field sorted by Morton code put 40
+// consecutive triangles into cells 4.5 units across where 2.6 are possible -- and wide cells are what defeats the culling
+// certificates of rt_mfma.hpp: their bounds are per tile).  Only tightness depends on the order: hits merge by VISIT index.
+// Non-finite centroids sort as 0.  Deterministic: ties break by visit index.
+static std::vector<uint32_t> kd_order(const rtgl_context *ctx, const std::vector<uint32_t> &visit_tri, uint32_t group_tris)
 {
     const size_t n = visit_tri.size();
     const float *vx = reinterpret_cast<const float *>(ctx->h_vertices.data());
     std::vector<float> cen(3 * n);
-    float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
     for (size_t v = 0; v < n; ++v)
         for (int a = 0; a < 3; ++a) {
             const float *t = vx + (size_t)visit_tri[v] * 12;
-            float c = (t[a] + t[4 + a] + t[8 + a]) * (1.0f / 3.0f);
-            cen[3 * v + a] = c;
-            if (c == c && c > -1.0e30f && c < 1.0e30f) { lo[a] = std::min(lo[a], c); hi[a] = std::max(hi[a], c); }
+            const float c = (t[a] + t[4 + a] + t[8 + a]) * (1.0f / 3.0f);
+            cen[3 * v + a] = (c == c && c > -1.0e30f && c < 1.0e30f) ? c : 0.0f;
         }
-    auto spread = [](uint64_t x) { x &= 0x3ff; x = (x | (x << 16)) & 0x30000ff; x = (x | (x << 8)) & 0x300f00f; x = (x | (x << 4)) & 0x30c30c3; x = (x | (x << 2)) & 0x9249249; return x; };
-    std::vector<std::pair<uint64_t, uint32_t>> keyed(n);
-    const float ext = std::max(hi[0] - lo[0], std::max(hi[1] - lo[1], hi[2] - lo[2]));
-    for (size_t v = 0; v < n; ++v) {
-        uint64_t code = 0;
-        for (int a = 0; a < 3; ++a) {
-            const float c = cen[3 * v + a];
-            uint64_t q = 0;
-            if (c == c && ext > 0.0f && c >= lo[a] && c <= hi[a]) q = (uint64_t)std::min(1023.0f, (c - lo[a]) / ext * 1023.0f);
-            code |= spread(q) << a;
-        }
-        keyed[v] = {code, (uint32_t)v};
-    }
-    std::sort(keyed.begin(), keyed.end());
     std::vector<uint32_t> order(n);
-    for (size_t i = 0; i < n; ++i) order[i] = keyed[i].second;
+    for (size_t i = 0; i < n; ++i) order[i] = (uint32_t)i;
+    std::vector<std::pair<size_t, size_t>> todo;
+    if (n) todo.emplace_back(0, n);
+    while (!todo.empty()) {
+        const size_t lo = todo.back().first, hi = todo.back().second, m = hi - lo;
+        todo.pop_back();
+        if (m <= (size_t)kMfTileTris) continue;
+        const size_t unit = m > group_tris ? group_tris : (m > (size_t)kMfQuadTris ? (size_t)kMfQuadTris : (size_t)kMfTileTris);
+        const size_t nl = ((m / 2 + unit - 1) / unit) * unit;           // in [unit, m): m > unit
+        float bl[3] = {3.0e38f, 3.0e38f, 3.0e38f}, bh[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+        for (size_t i = lo; i < hi; ++i)
+            for (int a = 0; a < 3; ++a) { const float c = cen[3 * (size_t)order[i] + a]; bl[a] = std::min(bl[a], c); bh[a] = std::max(bh[a], c); }
+        int ax = 0;
+        for (int a = 1; a < 3; ++a) if (bh[a] - bl[a] > bh[ax] - bl[ax]) ax = a;
+        std::nth_element(order.begin() + lo, order.begin() + lo + nl, order.begin() + hi, [&](uint32_t p, uint32_t q) {
+            const float cp = cen[3 * (size_t)p + ax], cq = cen[3 * (size_t)q + ax];
+            return cp < cq || (cp == cq && p < q);
+        });
+        todo.emplace_back(lo, lo + nl);
+        todo.emplace_back(lo + nl, hi);
+    }
     return order;
 }
 
@@ -687,7 +694,7 @@ static int rebuild_triangles(rtgl_context *ctx)
         ctx->mf_group_quads = ctx->group_explicit ? (uint32_t)ctx->opt_mf_group_quads : 32u;
         const uint32_t group_tris = ctx->mf_group_quads * kMfQuadTris;
         ctx->n_mf_groups = (ctx->n_tri_visits + group_tris - 1) / group_tris;
-        const std::vector<uint32_t> order = morton_order(ctx, visit_tri);
+        const std::vector<uint32_t> order = kd_order(ctx, visit_tri, group_tris);
         HIPCHK(ctx, hipMalloc((void **)&ctx->d_mf_order, order.size() * 4));
         HIPCHK(ctx, hipMemcpyAsync(ctx->d_mf_order, order.data(), order.size() * 4, hipMemcpyHostToDevice, ctx->stream));
         HIPCHK(ctx, hipMalloc((void **)&ctx->d_edges_s, (size_t)ctx->n_tri_visits * sizeof(TriEdges)));
@@ -702,12 +709,12 @@ static int rebuild_triangles(rtgl_context *ctx)
         hipLaunchKernelGGL(prepare_mfma_kernel, dim3(ctx->n_mf_groups), dim3(64), 0, ctx->stream, ctx->d_vertices, d_visit,
                            ctx->d_mf_order, ctx->n_tri_visits, ctx->n_mf_groups, ctx->mf_group_quads, ctx->d_mf_groups, ctx->d_mf_A);
         HIPCHK(ctx, hipGetLastError());
-        // packet-culling records, one per quad of the storage order (+ one group's worth of slack: a chunk copies whole records)
-        const uint32_t n_quads_alloc = ctx->n_mf_groups * ctx->mf_group_quads + 32u;
-        HIPCHK(ctx, hipMalloc((void **)&ctx->d_mf_cull, (size_t)n_quads_alloc * sizeof(MfCull)));
-        HIPCHK(ctx, hipMemsetAsync(ctx->d_mf_cull, 0, (size_t)n_quads_alloc * sizeof(MfCull), ctx->stream));
-        hipLaunchKernelGGL(prepare_cull_kernel, dim3(ctx->n_mf_groups * ctx->mf_group_quads), dim3(64), 0, ctx->stream, ctx->d_vertices, d_visit,
-                           ctx->d_mf_order, ctx->n_tri_visits, ctx->n_mf_groups * ctx->mf_group_quads, ctx->d_mf_cull);
+        // packet-culling records, one per tile of the storage order (all-zero records -- unusable -- behind the last one)
+        const uint32_t n_tiles_all = ctx->n_mf_groups * ctx->mf_group_quads * (uint32_t)kMfQuadTiles, n_tiles_alloc = n_tiles_all + 128u;
+        HIPCHK(ctx, hipMalloc((void **)&ctx->d_mf_cull, (size_t)n_tiles_alloc * sizeof(MfCull)));
+        HIPCHK(ctx, hipMemsetAsync(ctx->d_mf_cull, 0, (size_t)n_tiles_alloc * sizeof(MfCull), ctx->stream));
+        hipLaunchKernelGGL(prepare_cull_kernel, dim3(n_tiles_all), dim3(64), 0, ctx->stream, ctx->d_vertices, d_visit,
+                           ctx->d_mf_order, ctx->n_tri_visits, n_tiles_all, ctx->d_mf_cull);
         HIPCHK(ctx, hipGetLastError());
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
         HIPCHK(ctx, hipFree(d_visit));
@@ -751,9 +758,9 @@ static int ensure_wave_buffers(rtgl_context *ctx, uint32_t n0, uint32_t max_boun
             ctx->cand_regions = need_regions; ctx->cand_region_pairs = ctx->cand_region_target;
             HIPCHK(ctx, hipMalloc((void **)&ctx->d_cand, ((size_t)need_regions * ctx->cand_region_pairs) * sizeof(uint2) + (size_t)need_regions * sizeof(uint32_t) + 256));
         }
-        {                                                    // packet culling: one bit per (granule of 128 rays, quad); + 16 granules read ahead of the last one
+        {                                                    // packet culling: one bit per (granule of 128 rays, tile); + 16 granules read ahead of the last one
             const uint32_t real_quads = std::min(ctx->n_mf_groups * ctx->mf_group_quads, (ctx->n_tri_visits + (uint32_t)kMfQuadTris - 1) / (uint32_t)kMfQuadTris);
-            ctx->wb.keep_words = std::max(1u, (real_quads + 31u) / 32u);
+            ctx->wb.keep_words = std::max(1u, (real_quads * (uint32_t)kMfQuadTiles + 31u) / 32u);
             const size_t need = ((size_t)n0 / 128 + 16) * ctx->wb.keep_words;
             if (ctx->keep_capacity < need) {
                 if (ctx->d_keep) { HIPCHK(ctx, hipFree(ctx->d_keep)); ctx->d_keep = nullptr; }
@@ -772,7 +779,7 @@ static int ensure_wave_buffers(rtgl_context *ctx, uint32_t n0, uint32_t max_boun
             }
             ctx->wb.sched = ctx->d_sched;
         }
-        ctx->wb.items = ctx->d_items; ctx->wb.item_counts = reinterpret_cast<uint32_t *>(ctx->d_items);     // (allocated by the first culled launch)
+        ctx->wb.items = reinterpret_cast<uint32_t *>(ctx->d_items); ctx->wb.item_counts = reinterpret_cast<uint32_t *>(ctx->d_items);     // (allocated by the first culled launch)
         ctx->wb.cand = ctx->d_cand;
         ctx->wb.cand_counts = reinterpret_cast<uint32_t *>(ctx->d_cand + (size_t)ctx->cand_regions * ctx->cand_region_pairs);
         ctx->wb.cand_region = ctx->cand_region_pairs;
@@ -905,18 +912,18 @@ static int launch_intersect_solo(rtgl_context *ctx, const SceneView &sc, uint32_
     // packet culling pays where the 128 rays of a wave are coherent: the camera rays (option "cull": 0 never, 1 bounce 0 (default), 2 every bounce)
     const int cull = ctx->opt_cull == 2 || (ctx->opt_cull == 1 && bounce == 0);
     if (cull) {
-        hipLaunchKernelGGL(packet_cull_kernel, dim3(std::max(1u, std::min((est_gran + 3u) / 4u, 8192u))), dim3(256), 0, ctx->stream, ctx->wb, ctx->d_mf_cull, real_quads, bounce);
+        hipLaunchKernelGGL(packet_cull_kernel, dim3(std::max(1u, std::min((est_gran + 3u) / 4u, 8192u))), dim3(256), 0, ctx->stream, ctx->wb, ctx->d_mf_cull, real_quads * (uint32_t)kMfQuadTiles, bounce);
         if (dynamic) {
         // work items of the culled launch: [one count per chunk][chunks x (granules of the whole image) entries]
         const uint32_t stride = n0 / Cfg::kRaysPerWave + 1u;
-        const size_t head = ((size_t)ctx->wb.sched_stride * sizeof(uint32_t) + 255) & ~(size_t)255, need = head + (size_t)chunks * stride * sizeof(uint2);
+        const size_t head = ((size_t)ctx->wb.sched_stride * sizeof(uint32_t) + 255) & ~(size_t)255, need = head + (size_t)chunks * stride * sizeof(uint32_t);
         if (ctx->items_capacity < need) {
             if (ctx->d_items) { HIPCHK(ctx, hipFree(ctx->d_items)); ctx->d_items = nullptr; }
             HIPCHK(ctx, hipMalloc((void **)&ctx->d_items, need));
             ctx->items_capacity = need;
         }
         ctx->wb.item_counts = reinterpret_cast<uint32_t *>(ctx->d_items);
-        ctx->wb.items = reinterpret_cast<uint2 *>(reinterpret_cast<uint8_t *>(ctx->d_items) + head);
+        ctx->wb.items = reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(ctx->d_items) + head);
         ctx->wb.items_stride = stride;
         HIPCHK(ctx, hipMemsetAsync(ctx->wb.item_counts, 0, (size_t)chunks * sizeof(uint32_t), ctx->stream));
         const dim3 igrid(std::max(1u, std::min((est_gran + 255u) / 256u, 1024u)), chunks);

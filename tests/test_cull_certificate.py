@@ -1,18 +1,20 @@
-"""The packet-culling certificate (raytracer.glsl_amd/csrc/rt_mfma.hpp `MfCull`) against the reference's own
-triangle test, on the CPU.
+"""The packet-culling certificates (raytracer.glsl_amd/csrc/rt_mfma.hpp `MfCull` / `mf_certified`) against the
+reference's own triangle test, on the CPU.
 
-The HIP path may skip a quad of 40 triangles for a wave of 128 rays only if the reference's edge test
+The HIP path may skip a tile of 10 triangles for a granule of 128 rays only if the reference's edge test
 (/root/reference/shaders/raytracer.glsl:226-245: all three `dot(e_k, cv) + dot(m_k, d) > 0`, evaluated in fp32) rejects every
-(ray, triangle) pair.  This file restates the certificate in numpy (fp32, the device formulas) and the reference's test in fp32
-with the pinned operation order, and checks on random and adversarial inputs that
+(ray, triangle) pair.  This file restates the tile record and the three certificates -- (A) plane form, (K) back faces, (B) moment
+form -- in numpy (fp32, the device formulas) and the reference's test in fp32 with the pinned operation order, and checks on random
+and adversarial inputs that
 
-  * whenever the certificate fires, the reference rejects every pair (including rays placed IN the plane of a far triangle of
-    the quad, +- a few ulps: the case a purely geometric "misses the bounding sphere" cull gets wrong);
-  * the identity the proof rests on, F_k = -(d.N) beta_k, holds;
-  * the certificate is not vacuous (it fires for most far packets on a bumpy height field).
+  * whenever a certificate fires, the reference rejects every pair (including rays placed IN the plane of a far triangle of
+    the tile, +- a few ulps: the case a purely geometric "misses the bounding sphere" cull gets wrong), for camera-like packets and
+    for packets of secondary rays leaving the surface in all directions;
+  * the identities the proofs rest on hold: F_k = -(d.N) beta_k and F_k = e_k.w - (d.N)/3 with w = d x (o - G);
+  * the certificates are not vacuous (they fire for most far packets on a bumpy height field).
 
 The device implementation itself is checked on the GPU by image parity with the cull on / off / on every bounce
-(tests/test_gpu_fullsize.py, test_gpu_golden.py, test_gpu_parity.py).  Parity of the certificate's THEORY is what is tested here.
+(tests/test_gpu_fullsize.py, test_gpu_golden.py, test_gpu_parity.py).  Parity of the certificates' THEORY is what is tested here.
 """
 import numpy as np
 import pytest
@@ -45,24 +47,48 @@ def reference_accepts(tri, o, d):
 
 
 def cull_record(tri):
-    """prepare_cull_kernel: bounding sphere, box of the unit normals, N_min, shape, E, Pw (fp32 with the kernel's slack)."""
+    """prepare_cull_kernel: bounding sphere, centroid radius, gnomonic rectangle of the unit normals in a principal tangent frame,
+    N_min, shape, h_min, l_max, E, Pw (fp32 with the kernel's slack).  `usable` False = the kernel's Nmin = 0."""
     tri = tri.astype(f32)
     p = tri.reshape(-1, 3)
     c = f32(0.5) * p.min(0) + f32(0.5) * p.max(0)
     R = np.sqrt(((p - c) ** 2).sum(1)).max() * f32(1.0001) + f32(1e-30)
+    G = (tri[:, 0] + tri[:, 1] + tri[:, 2]) * f32(1.0 / 3.0) - c
+    Rc = np.sqrt(dot3(G, G)).max() * f32(1.0001) + f32(1e-30)
     e0, e1, e2 = tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 1], tri[:, 0] - tri[:, 2]
     N = cross3(e0, -e2)
     nn = np.sqrt(dot3(N, N))
-    nh = N / nn[:, None]
-    l0, l1, l2 = (np.sqrt(dot3(e, e)) for e in (e0, e1, e2))
-    c0, c1, c2 = -dot3(e0, e2) / (l0 * l2), -dot3(e1, e0) / (l1 * l0), -dot3(e2, e1) / (l2 * l1)
-    cmax = np.minimum(f32(1), np.maximum(c0, np.maximum(c1, c2)))
-    s = np.sqrt(np.maximum(f32(0), f32(0.5) * (f32(1) - cmax)))
-    shape = (f32(0.999) * s * np.minimum(l0, np.minimum(l1, l2)) / nn).min()
+    with np.errstate(divide="ignore", invalid="ignore"):
+        nh = N / nn[:, None]
+        l0, l1, l2 = (np.sqrt(dot3(e, e)) for e in (e0, e1, e2))
+        c0, c1, c2 = -dot3(e0, e2) / (l0 * l2), -dot3(e1, e0) / (l1 * l0), -dot3(e2, e1) / (l2 * l1)
+        cmax = np.minimum(f32(1), np.maximum(c0, np.maximum(c1, c2)))
+        s = np.sqrt(np.maximum(f32(0), f32(0.5) * (f32(1) - cmax)))
+        E = np.maximum(l0, np.maximum(l1, l2))
+        shape = (f32(0.999) * s * np.minimum(l0, np.minimum(l1, l2)) / nn).min()
+        hmin = (f32(0.999) * nn / E).min()
     an = [np.sqrt(dot3(tri[:, k], tri[:, k])) for k in range(3)]
-    return dict(c=c, R=f32(R), nlo=nh.min(0) - f32(1e-6), nhi=nh.max(0) + f32(1e-6), Nmin=nn.min() * f32(0.999), shape=f32(shape),
-                E=np.maximum(l0, np.maximum(l1, l2)).max() * f32(1.001),
-                Pw=max((an[0] * an[1]).max(), (an[1] * an[2]).max(), (an[2] * an[0]).max()) * f32(1.001))
+    bad = not np.isfinite(nh).all() or not np.isfinite(p).all()
+    a = nh.sum(0)
+    al = np.sqrt(dot3(a, a))
+    a = a / al if al > 0 else np.array([0, 0, 1], f32)
+    ca = dot3(nh, a[None])
+    bad |= not (al > 0) or not (ca > f32(0.1)).all()
+    ref = np.array([1, 0, 0], f32) if abs(a[0]) < 0.7 else np.array([0, 1, 0], f32)
+    b1 = cross3(a, ref); b1 = b1 / np.sqrt(dot3(b1, b1)); b2 = cross3(a, b1)
+    ica = f32(1) / np.maximum(ca, f32(0.1))
+    gu, gv = dot3(nh, b1[None]) * ica, dot3(nh, b2[None]) * ica
+    phi = f32(0.5) * np.arctan2(f32(2) * (gu * gv).sum(), (gu * gu).sum() - (gv * gv).sum())
+    t1 = np.cos(phi) * b1 + np.sin(phi) * b2; t1 = (t1 / np.sqrt(dot3(t1, t1))).astype(f32)
+    t2 = cross3(a, t1); t2 = (t2 / np.sqrt(dot3(t2, t2))).astype(f32)
+    X = np.abs(dot3(nh, t1[None]) * ica).max() * f32(1.001) + f32(1e-5)
+    Y = np.abs(dot3(nh, t2[None]) * ica).max() * f32(1.001) + f32(1e-5)
+    bad |= not (X < 16) or not (Y < 16)
+    return dict(c=c, R=f32(R), Rc=f32(Rc), a=a.astype(f32), t1=t1, t2=t2, X=f32(X), Y=f32(Y), usable=not bad,
+                Nmin=f32(0) if bad else nn.min() * f32(0.999), shape=f32(0) if bad else f32(shape), hmin=f32(0) if bad else f32(hmin),
+                lmax=E.max() * f32(1.001), E=E.max() * f32(1.001),
+                Pw=max((an[0] * an[1]).max(), (an[1] * an[2]).max(), (an[2] * an[0]).max()) * f32(1.001),
+                inv_len=f32(0.9999) / np.sqrt(f32(1) + f32(X) * f32(X) + f32(Y) * f32(Y)))
 
 
 def packet_bounds(o, d):
@@ -78,42 +104,84 @@ def packet_bounds(o, d):
     return dict(O=O, D=D, ro=f32(ro), sigma=f32(sigma), On=np.sqrt(dot3(O, O)) * f32(1.0001) + f32(ro), usable=bool(Dl > 0.25))
 
 
+def max_dot(rec, wa, w1, w2, wn):
+    """mf_max_dot: upper bound of max over the record's normals of w.n^ (w given by its components along a, |t1|, |t2|)"""
+    X, Y = rec["X"], rec["Y"]
+    if wa > 0 and w1 <= X * wa and w2 <= Y * wa:
+        return wn
+    num = wa + X * w1 + Y * w2
+    corner = num * rec["inv_len"] * (f32(1.0003) if num > 0 else f32(1))
+    A, B = wa + X * w1, f32(1) + X * X
+    A2, B2 = wa + Y * w2, f32(1) + Y * Y
+    e1 = np.sqrt(A * A / B + w2 * w2) if (A > 0 and w2 * B <= Y * A) else -np.inf
+    e2 = np.sqrt(A2 * A2 / B2 + w1 * w1) if (A2 > 0 and w1 * B2 <= X * A2) else -np.inf
+    return min(max(corner, e1, e2) + f32(1e-4) * wn, wn)
+
+
+def certificates(rec, pk):
+    """mf_certified: (A, K, B) for one tile record and one packet"""
+    if not pk["usable"] or not rec["usable"]:
+        return False, False, False
+    g = (pk["O"] - rec["c"]).astype(f32)
+    L = np.sqrt(dot3(g, g)) * f32(1.0001)
+    nz = f32(9.5367431640625e-07) * (rec["E"] * pk["On"] + rec["Pw"]) * f32(1.01)
+    D, a, t1, t2 = pk["D"], rec["a"], rec["t1"], rec["t2"]
+    Da, D1, D2 = dot3(D, a), abs(dot3(D, t1)), abs(dot3(D, t2))
+    spread = rec["X"] * D1 + rec["Y"] * D2
+    num_pos, num_neg = Da - spread, -Da - spread
+    lo_pos = (num_pos * rec["inv_len"] if num_pos > 0 else num_pos) - pk["sigma"] - f32(1e-5)
+    lo_neg = (num_neg * rec["inv_len"] if num_neg > 0 else num_neg) - pk["sigma"] - f32(1e-5)
+    cert_k = bool(lo_pos > 0 and (rec["Nmin"] * lo_pos) * f32(0.3333) * f32(0.99) >= nz)
+    W = cross3(D, g)
+    Wn = np.sqrt(dot3(W, W))
+    delta = (Wn * f32(0.9999) - L * pk["sigma"]) - (pk["ro"] + rec["R"]) - f32(1e-5) * (L + pk["ro"] + rec["R"])
+    cmin = max(lo_pos, lo_neg)
+    lhs_a = (rec["Nmin"] * cmin) * min(f32(0.3333), delta * rec["shape"]) * f32(0.99)
+    cert_a = bool(delta > 0 and cmin > 0 and lhs_a > 0 and lhs_a >= nz)
+    slack = (pk["ro"] + rec["Rc"]) + L * pk["sigma"] + f32(1e-5) * (L + pk["ro"] + rec["Rc"])
+    Wa, W1, W2 = dot3(W, a), abs(dot3(W, t1)), abs(dot3(W, t2))
+    Wn_up, Wn_lo = Wn * f32(1.0001), Wn * f32(0.9999)
+    M = max(max_dot(rec, Wa, W1, W2, Wn_up), max_dot(rec, -Wa, W1, W2, Wn_up))
+    wp = np.sqrt(max(f32(0), Wn_lo * Wn_lo - M * M)) * f32(0.9999) - slack
+    dist = Wn_lo - slack
+    with np.errstate(divide="ignore", invalid="ignore"):
+        lhs_b = (rec["hmin"] * wp) * (f32(0.5) - (rec["lmax"] * f32(0.33334)) / dist * f32(1.0001)) * f32(0.99)
+    cert_b = bool(wp > 0 and dist > f32(1.3334) * rec["lmax"] and M < Wn_lo and lhs_b > 0 and lhs_b >= nz)
+    return cert_a, cert_k, cert_b
+
+
 def certified(rec, pk):
-    """the per-quad test of packet_cull_kernel"""
-    if not pk["usable"]:
-        return False
-    w = rec["c"] - pk["O"]
-    L = np.sqrt(dot3(w, w)) * f32(1.0001)
-    crn = np.sqrt(dot3(cross3(w, pk["D"]), cross3(w, pk["D"])))
-    delta = (crn * f32(0.9999) - L * pk["sigma"]) - (pk["ro"] + rec["R"]) - f32(1e-5) * (L + pk["ro"] + rec["R"])
-    D = pk["D"]
-    plo = sum(min(D[i] * rec["nlo"][i], D[i] * rec["nhi"][i]) for i in (2, 1, 0))
-    phi = sum(max(D[i] * rec["nlo"][i], D[i] * rec["nhi"][i]) for i in (2, 1, 0))
-    cmin = (plo if plo > 0 else (-phi if phi < 0 else f32(-1))) - pk["sigma"] - f32(1e-5)
-    lhs = (rec["Nmin"] * cmin) * min(f32(0.3333), delta * rec["shape"]) * f32(0.99)
-    rhs = f32(9.5367431640625e-07) * (rec["E"] * pk["On"] + rec["Pw"]) * f32(1.01)
-    return bool(delta > 0 and cmin > 0 and rec["Nmin"] > 0 and lhs > 0 and lhs >= rhs)
+    return any(certificates(rec, pk))
 
 
-def bumpy_quad(rng, amp):
-    """40 triangles of a height field patch (4 x 5 cells), somewhere in a 40 x 20 scene, wound like the benchmark mesh"""
+def bumpy_tiles(rng, amp):
+    """40 triangles of a height field patch (4 x 5 cells), somewhere in a 40 x 20 scene, wound like the benchmark mesh, as four
+    tiles of 10 triangles (5 neighbouring cells each)"""
     x0, y0 = rng.uniform(-18, 14), rng.uniform(-12, 2)
     cell = rng.uniform(0.2, 0.8)
     ph = rng.uniform(0, 6.28, 2)
 
     def z(x, y):
         return 5.0 + amp * np.sin(0.75 * x + ph[0]) * np.cos(0.5 * y + ph[1])
-    tris = []
+    tiles = []
     for i in range(4):
+        tris = []
         for j in range(5):
             xs, ys = x0 + i * cell, y0 + j * cell
             a, b, c, d = [(xs, ys), (xs + cell, ys), (xs + cell, ys + cell), (xs, ys + cell)]
             P = [np.array([q[0], q[1], z(*q)]) for q in (a, b, c, d)]
             tris += [[P[0], P[2], P[1]], [P[0], P[3], P[2]]]
-    return np.array(tris, np.float64)
+        tiles.append(np.array(tris, np.float64))
+    return tiles
 
 
-def random_packet(rng, quad, n=32):
+def soup_tile(rng):
+    """10 unrelated triangles in a small region: normals all over the sphere (mostly an unusable record)"""
+    c = rng.uniform(-10, 10, 3)
+    return c + rng.normal(size=(10, 3, 3)) * rng.uniform(0.1, 1.0)
+
+
+def random_packet(rng, tile, n=32):
     """rays from a small origin region towards (or past) the scene, narrow cone"""
     O = np.array([rng.uniform(-5, 5), rng.uniform(-5, 5), rng.uniform(-40, -20)])
     target = np.array([rng.uniform(-22, 22), rng.uniform(-15, 8), 5.0])
@@ -124,9 +192,23 @@ def random_packet(rng, quad, n=32):
     return o, d
 
 
-def coplanar_packet(rng, quad, n=32, tilt=1e-6):
-    """adversarial: rays IN the plane of one triangle of the quad (nudged by a few fp32 ulps), starting far away, passing beside it"""
-    t = quad[rng.integers(len(quad))]
+def secondary_packet(rng, tile, n=32):
+    """rays leaving a patch of the surface (z ~ 5, anywhere in the scene or right beside the tile) into a cone of any axis: what the
+    binned queues of bounces >= 1 look like.  Both sides of the surface, grazing directions included."""
+    near = rng.random() < 0.4
+    cen = tile.reshape(-1, 3).mean(0)
+    O = cen + rng.normal(size=3) * np.array([3.0, 3.0, 0.5]) if near else np.array([rng.uniform(-20, 20), rng.uniform(-14, 6), 5.0 + rng.uniform(-2, 2)])
+    D = rng.normal(size=3); D /= np.linalg.norm(D)
+    if rng.random() < 0.3: D[2] *= 0.05                   # grazing along the field
+    o = O + rng.normal(size=(n, 3)) * rng.choice([1e-2, 0.3, 1.5])
+    d = D + rng.normal(size=(n, 3)) * rng.choice([1e-3, 0.05, 0.2])
+    d *= rng.uniform(0.5, 2.0, size=(n, 1))
+    return o, d
+
+
+def coplanar_packet(rng, tile, n=32, tilt=1e-6):
+    """adversarial: rays IN the plane of one triangle of the tile (nudged by a few fp32 ulps), starting far away, passing beside it"""
+    t = tile[rng.integers(len(tile))]
     nrm = np.cross(t[1] - t[0], t[2] - t[0]); nrm /= np.linalg.norm(nrm)
     u = t[1] - t[0]; u /= np.linalg.norm(u)
     v = np.cross(nrm, u)
@@ -153,35 +235,109 @@ def test_edge_functions_are_minus_d_dot_N_times_barycentrics():
             assert abs(F + np.dot(d, N) * beta) <= 1e-9 * (1 + abs(F))
 
 
+def test_moment_form_of_the_edge_functions_and_its_bound():
+    """F_k = e_k.w - (d.N)/3 with w = d x (o - G); min_k F_k <= -h_min |w_p| / 2 + |d.N| / 3 (certificate B, float64)"""
+    rng = np.random.default_rng(2)
+    for _ in range(500):
+        t = rng.normal(size=(3, 3)) * rng.uniform(0.1, 3)
+        o, d = rng.normal(size=3) * 10, rng.normal(size=3)
+        d /= np.linalg.norm(d)
+        N = np.cross(t[1] - t[0], t[2] - t[0]); nh = N / np.linalg.norm(N)
+        G = t.mean(0)
+        w = np.cross(d, o - G)
+        F = []
+        for k in range(3):
+            a = (k + 1) % 3
+            Fk = np.dot(t[a] - t[k], np.cross(d, o)) + np.dot(np.cross(t[a], t[k]), d)
+            assert abs(Fk - (np.dot(t[a] - t[k], w) - np.dot(d, N) / 3)) <= 1e-9 * (1 + abs(Fk))
+            F.append(Fk)
+        l = [np.linalg.norm(t[(k + 1) % 3] - t[k]) for k in range(3)]
+        hmin = np.linalg.norm(N) / max(l)
+        wp = np.linalg.norm(w - np.dot(w, nh) * nh)
+        assert min(F) <= -hmin * wp / 2 + abs(np.dot(d, N)) / 3 + 1e-9
+        assert abs(np.dot(d, nh)) <= wp / np.linalg.norm(w) + 1e-9
+
+
+def test_max_dot_bounds_every_normal_of_the_rectangle():
+    rng = np.random.default_rng(5)
+    for _ in range(300):
+        tile = bumpy_tiles(rng, rng.choice([0.0, 0.5, 2.0]))[rng.integers(4)]
+        rec = cull_record(tile)
+        assert rec["usable"]
+        N = np.cross(tile[:, 1] - tile[:, 0], tile[:, 2] - tile[:, 0]); nh = N / np.linalg.norm(N, axis=1, keepdims=True)
+        # the record's frame is orthonormal and its rectangle holds the tile's normals
+        a, t1, t2 = (rec[k].astype(np.float64) for k in ("a", "t1", "t2"))
+        assert abs(a @ t1) < 1e-5 and abs(a @ t2) < 1e-5 and abs(t1 @ t2) < 1e-5
+        assert (np.abs(nh @ t1 / (nh @ a)) <= rec["X"]).all() and (np.abs(nh @ t2 / (nh @ a)) <= rec["Y"]).all()
+        for _ in range(20):
+            w = rng.normal(size=3) * rng.uniform(0.1, 10)
+            if rng.random() < 0.3: w = nh[rng.integers(10)] * np.linalg.norm(w) + rng.normal(size=3) * 1e-3
+            wn = f32(np.linalg.norm(w) * 1.0001)
+            got = max_dot(rec, f32(w @ a), f32(abs(w @ t1)), f32(abs(w @ t2)), wn)
+            # dense sample of the rectangle + the tile's own normals
+            xs = np.linspace(-rec["X"], rec["X"], 41)[:, None]; ys = np.linspace(-rec["Y"], rec["Y"], 41)[None, :]
+            f = ((w @ a) + xs * (w @ t1) + ys * (w @ t2)) / np.sqrt(1 + xs * xs + ys * ys)
+            assert f.max() <= got + 1e-6 * wn and (nh @ w).max() <= got + 1e-6 * wn
+
+
 @pytest.mark.parametrize("amp", [0.0, 0.5, 2.0])
 def test_certified_packets_are_rejected_by_the_reference_test(amp):
     rng = np.random.default_rng(int(amp * 10) + 7)
-    fired = tried = 0
+    fired = {"A": 0, "K": 0, "B": 0}
+    tried = any_fired = 0
+    for it in range(250):
+        for tile in bumpy_tiles(rng, amp):
+            rec = cull_record(tile)
+            for make in (random_packet, secondary_packet, secondary_packet, coplanar_packet):
+                o, d = make(rng, tile)
+                pk = packet_bounds(o, d)
+                tried += 1
+                ca, ck, cb = certificates(rec, pk)
+                fired["A"] += ca; fired["K"] += ck; fired["B"] += cb
+                if ca or ck or cb:
+                    any_fired += 1
+                    acc = reference_accepts(tile, o, d)
+                    assert not acc.any(), f"certificate {(ca, ck, cb)} fired but the reference accepts {int(acc.sum())} pairs (iteration {it}, {make.__name__})"
+    assert any_fired > 0.3 * tried, f"certificates fired for {any_fired} of {tried} packets only"
+    assert all(v > 0 for v in fired.values()), fired
+
+
+def test_certificates_on_triangle_soups_and_degenerate_tiles():
+    """unrelated triangles (normals all over the sphere), needles, duplicated and zero-area triangles, non-finite vertices: the record is
+    unusable or the certificates stay sound"""
+    rng = np.random.default_rng(11)
+    fired = 0
     for it in range(400):
-        quad = bumpy_quad(rng, amp)
-        rec = cull_record(quad)
-        for make in (random_packet, random_packet, coplanar_packet):
-            o, d = make(rng, quad)
+        tile = soup_tile(rng)
+        kind = it % 4
+        if kind == 1: tile[3] = tile[2]                                   # duplicate
+        if kind == 2: tile[5, 2] = tile[5, 1]                             # zero area
+        if kind == 3: tile[:, :, 2] *= 1e-3                               # nearly coplanar soup: usable record, tiny normal spread
+        rec = cull_record(tile)
+        for make in (random_packet, secondary_packet, coplanar_packet):
+            o, d = make(rng, tile)
             pk = packet_bounds(o, d)
-            tried += 1
             if certified(rec, pk):
                 fired += 1
-                acc = reference_accepts(quad, o, d)
-                assert not acc.any(), f"certificate fired but the reference accepts {int(acc.sum())} pairs (iteration {it}, {make.__name__})"
-    assert fired > 0.3 * tried, f"certificate fired for {fired} of {tried} packets only"
+                assert not reference_accepts(tile, o, d).any()
+    bad = soup_tile(rng); bad[4, 1, 0] = np.nan
+    assert not cull_record(bad)["usable"]
+    bad = soup_tile(rng); bad[4, 1, 0] = 1e20
+    assert not certified(cull_record(bad), packet_bounds(*random_packet(rng, bad)))
+    assert fired > 0
 
 
 def test_rays_in_the_plane_of_a_far_triangle_are_never_certified_but_can_be_accepted():
-    """The reason the certificate lives in edge-function space: for rays within rounding noise of a far triangle's plane the
-    reference's three edge values are noise, and it does accept some of them.  The certificate must not fire for such packets."""
+    """The reason the certificates live in edge-function space: for rays within rounding noise of a far triangle's plane the
+    reference's three edge values are noise, and it does accept some of them.  No certificate may fire for such packets."""
     rng = np.random.default_rng(3)
     accepted = fired = 0
     for _ in range(300):
-        quad = bumpy_quad(rng, 2.0)
-        rec = cull_record(quad)
-        o, d = coplanar_packet(rng, quad, n=64, tilt=0.0)      # exactly in the plane in float64: what is left after rounding to fp32 is noise
+        tile = bumpy_tiles(rng, 2.0)[rng.integers(4)]
+        rec = cull_record(tile)
+        o, d = coplanar_packet(rng, tile, n=64, tilt=0.0)      # exactly in the plane in float64: what is left after rounding to fp32 is noise
         pk = packet_bounds(o, d)
         fired += certified(rec, pk)
-        accepted += int(reference_accepts(quad, o, d).any())
+        accepted += int(reference_accepts(tile, o, d).any())
     assert fired == 0
     assert accepted > 0, "expected the fp32 reference test to accept at least one in-plane ray of a far triangle (it does on llvmpipe too)"

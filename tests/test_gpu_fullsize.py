@@ -126,10 +126,16 @@ def test_static_and_dynamic_work_distribution_agree(cfg_name, opts, rt):
     b, cb = render(rt, cfg_name, frames=2, options=opts, counters=True)[:2]
     assert (a.view(np.uint32) == b.view(np.uint32)).all()
     assert ca["segments"] == cb["segments"] and ca["triangle_tests"] == cb["triangle_tests"]
+    culls = any(k == "cull" for k, _ in opts)
     if not any(k == "mf_group_quads" for k, _ in opts):
-        assert ca["candidates"] == cb["candidates"]
-    if not any(k == "cull" for k, _ in opts):
-        assert ca["culled_tests"] == cb["culled_tests"]
+        # a tile culled for a granule yields no broad-phase survivors, so culling more bounces can only lose survivors -- pairs the
+        # certificates say the reference rejects, which the exact test would have dropped anyway (the images above are identical)
+        assert (cb["candidates"] <= ca["candidates"]) if culls else (ca["candidates"] == cb["candidates"])
+    if not culls:
+        if not any(k == "mf_group_quads" for k, _ in opts):      # (the storage order, hence the tiles, follows the group size)
+            assert ca["culled_tests"] == cb["culled_tests"]
+    else:
+        assert cb["culled_tests"] >= ca["culled_tests"]
 
 
 def test_c5_2160p_16_bounces_wide_dof(rt, oracle):
