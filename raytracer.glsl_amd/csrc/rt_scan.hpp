@@ -176,8 +176,14 @@ struct SoloCfg {
 //   * MFMA result -> VALU read of the same block: a block is read one stage after it was written, i.e. at least 3 MFMAs and 27
 //     VALU instructions later (>= 12 wait states needed for this 8-pass MFMA, tools/mfma_hazard_probe.hip); prologue and epilogue
 //     of a segment put a full s_nop 15 in between;
-//   * VALU write -> MFMA overwrite of a block (the M registers are outside the blocks) and MFMA source operands written by VALU:
-//     no wait states required on gfx950.
+//   * VALU write -> MFMA overwrite of a block (the M registers are outside the blocks): no wait states required on gfx950;
+//   * MFMA SOURCE operands written by a VALU instruction: ONE wait state -- the hardware does not interlock this.  With a v_mov of
+//     the A rows directly in front of the matrix instruction every lane multiplies a half-updated operand; one independent
+//     instruction in between and none does (tools/mfma_src_hazard_probe.hip, profiles/r3_mfma_src_hazard_probe.txt).  The compiler
+//     inserts that state for its own code, but a statement that BEGINS with a matrix instruction may find the compiler's copy of
+//     the tile rows right in front of it: every such statement starts with RT_HEAD (round 3: the list-driven tile loop lost hits
+//     in every culled configuration until it did).
+#define RT_HEAD "s_nop 1\n\t"
 #define RT_EXAM(PL, ML, KL, TH) \
     "v_min3_f32 v[" #ML "+0], v[" #PL "+0], v[" #PL "+1], v[" #PL "+2]\n\t" \
     "v_min3_f32 v[" #ML "+1], v[" #PL "+3], v[" #PL "+4], v[" #PL "+5]\n\t" \
@@ -196,7 +202,7 @@ struct SoloCfg {
 #define RT_K_CLOBBERS "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51"
 // two stages: tile t (operand AY) -> Y while X (tile t-1) is examined into MA; tile t+1 (operand AX) -> X while Y is examined into MB
 #define RT_TRIP(AY, AX) \
-    asm volatile(RT_STAGE_Y_TEXT("%[ay]") RT_STAGE_X_TEXT("%[ax]") RT_FOLD("%[anya]", 36) RT_FOLD("%[anyb]", 44) \
+    asm volatile(RT_HEAD RT_STAGE_Y_TEXT("%[ay]") RT_STAGE_X_TEXT("%[ax]") RT_FOLD("%[anya]", 36) RT_FOLD("%[anyb]", 44) \
                  : "+{v[128:143]}"(X0), "+{v[144:159]}"(X1), "+{v[160:175]}"(X2), "+{v[176:191]}"(X3), \
                    "=&{v[192:207]}"(Y0), "=&{v[208:223]}"(Y1), "=&{v[224:239]}"(Y2), "=&{v[240:255]}"(Y3), \
                    "=&{v[96:101]}"(MA0), "=&{v[104:109]}"(MA1), "=&{v[112:117]}"(MA2), "=&{v[120:125]}"(MA3), \
@@ -207,7 +213,7 @@ struct SoloCfg {
 // next row to read, advanced by two rows) right behind its first matrix instruction and waits for them at its end, when they have
 // long landed: nothing of the tile fetch is left for the scalar spot between two trips
 #define RT_TRIP_L(AY, AX, NY, NX, ADDR) \
-    asm volatile(RT_MFMA(192, "%[ay]", "%[b0]") "ds_read_b128 %[ny], %[addr]\n\tds_read_b128 %[nx], %[addr] offset:1024\n\tv_add_u32_e32 %[addr], 0x800, %[addr]\n\t" \
+    asm volatile(RT_HEAD RT_MFMA(192, "%[ay]", "%[b0]") "ds_read_b128 %[ny], %[addr]\n\tds_read_b128 %[nx], %[addr] offset:1024\n\tv_add_u32_e32 %[addr], 0x800, %[addr]\n\t" \
                  RT_EXAM(128, 96, 36, "%[t0]") RT_MFMA(208, "%[ay]", "%[b1]") RT_EXAM(144, 104, 38, "%[t1]") \
                  RT_MFMA(224, "%[ay]", "%[b2]") RT_EXAM(160, 112, 40, "%[t2]") RT_MFMA(240, "%[ay]", "%[b3]") RT_EXAM(176, 120, 42, "%[t3]") \
                  RT_STAGE_X_TEXT("%[ax]") "s_waitcnt lgkmcnt(0)\n\t" RT_FOLD("%[anya]", 36) RT_FOLD("%[anyb]", 44) \
@@ -218,27 +224,42 @@ struct SoloCfg {
                    [ny] "=&v"(NY), [nx] "=&v"(NX), [addr] "+v"(ADDR) \
                  : [ay] "v"(AY), [ax] "v"(AX), [b0] "v"(B0), [b1] "v"(B1), [b2] "v"(B2), [b3] "v"(B3), [t0] "v"(th0), [t1] "v"(th1), [t2] "v"(th2), [t3] "v"(th3) \
                  : RT_K_CLOBBERS, "memory")
+// the same trip for a LIST of tiles (culled bounces scan the kept tiles of a segment, wherever they are): the rows of the two tiles the
+// NEXT trip multiplies are read from two explicit LDS addresses
+#define RT_TRIP_G(AY, AX, NY, NX, ADDRY, ADDRX) \
+    asm volatile(RT_HEAD RT_MFMA(192, "%[ay]", "%[b0]") "ds_read_b128 %[ny], %[addry]\n\tds_read_b128 %[nx], %[addrx]\n\t" \
+                 RT_EXAM(128, 96, 36, "%[t0]") RT_MFMA(208, "%[ay]", "%[b1]") RT_EXAM(144, 104, 38, "%[t1]") \
+                 RT_MFMA(224, "%[ay]", "%[b2]") RT_EXAM(160, 112, 40, "%[t2]") RT_MFMA(240, "%[ay]", "%[b3]") RT_EXAM(176, 120, 42, "%[t3]") \
+                 RT_STAGE_X_TEXT("%[ax]") "s_waitcnt lgkmcnt(0)\n\t" RT_FOLD("%[anya]", 36) RT_FOLD("%[anyb]", 44) \
+                 : "+{v[128:143]}"(X0), "+{v[144:159]}"(X1), "+{v[160:175]}"(X2), "+{v[176:191]}"(X3), \
+                   "=&{v[192:207]}"(Y0), "=&{v[208:223]}"(Y1), "=&{v[224:239]}"(Y2), "=&{v[240:255]}"(Y3), \
+                   "=&{v[96:101]}"(MA0), "=&{v[104:109]}"(MA1), "=&{v[112:117]}"(MA2), "=&{v[120:125]}"(MA3), \
+                   "=&{v[64:69]}"(MB0), "=&{v[72:77]}"(MB1), "=&{v[80:85]}"(MB2), "=&{v[88:93]}"(MB3), [anya] "=&s"(any_a), [anyb] "=&s"(any_b), \
+                   [ny] "=&v"(NY), [nx] "=&v"(NX) \
+                 : [ay] "v"(AY), [ax] "v"(AX), [b0] "v"(B0), [b1] "v"(B1), [b2] "v"(B2), [b3] "v"(B3), [t0] "v"(th0), [t1] "v"(th1), [t2] "v"(th2), [t3] "v"(th3), \
+                   [addry] "v"(ADDRY), [addrx] "v"(ADDRX) \
+                 : RT_K_CLOBBERS, "memory")
 // a single stage (a segment with an even number of tiles ends with one), the products of a segment's first tile, and the
 // examination of its last one (nothing to overlap with)
 #define RT_STAGE_Y(AY) \
-    asm volatile(RT_STAGE_Y_TEXT("%[ay]") RT_FOLD("%[anya]", 36) \
+    asm volatile(RT_HEAD RT_STAGE_Y_TEXT("%[ay]") RT_FOLD("%[anya]", 36) \
                  : "=&{v[192:207]}"(Y0), "=&{v[208:223]}"(Y1), "=&{v[224:239]}"(Y2), "=&{v[240:255]}"(Y3), \
                    "=&{v[96:101]}"(MA0), "=&{v[104:109]}"(MA1), "=&{v[112:117]}"(MA2), "=&{v[120:125]}"(MA3), [anya] "=&s"(any_a) \
                  : "{v[128:143]}"(X0), "{v[144:159]}"(X1), "{v[160:175]}"(X2), "{v[176:191]}"(X3), \
                    [ay] "v"(AY), [b0] "v"(B0), [b1] "v"(B1), [b2] "v"(B2), [b3] "v"(B3), [t0] "v"(th0), [t1] "v"(th1), [t2] "v"(th2), [t3] "v"(th3) \
                  : RT_K_CLOBBERS)
 #define RT_PRODUCTS_X(AOP) \
-    asm volatile(RT_MFMA(128, "%[a]", "%[b0]") RT_MFMA(144, "%[a]", "%[b1]") RT_MFMA(160, "%[a]", "%[b2]") RT_MFMA(176, "%[a]", "%[b3]") "s_nop 15" \
+    asm volatile(RT_HEAD RT_MFMA(128, "%[a]", "%[b0]") RT_MFMA(144, "%[a]", "%[b1]") RT_MFMA(160, "%[a]", "%[b2]") RT_MFMA(176, "%[a]", "%[b3]") "s_nop 15" \
                  : "=&{v[128:143]}"(X0), "=&{v[144:159]}"(X1), "=&{v[160:175]}"(X2), "=&{v[176:191]}"(X3) \
                  : [a] "v"(AOP), [b0] "v"(B0), [b1] "v"(B1), [b2] "v"(B2), [b3] "v"(B3))
 #define RT_EXAMINE_X() \
-    asm volatile("s_nop 15\n\t" RT_EXAM(128, 96, 36, "%[t0]") RT_EXAM(144, 104, 38, "%[t1]") RT_EXAM(160, 112, 40, "%[t2]") RT_EXAM(176, 120, 42, "%[t3]") "s_nop 7" \
-                 : "=&{v[96:101]}"(MA0), "=&{v[104:109]}"(MA1), "=&{v[112:117]}"(MA2), "=&{v[120:125]}"(MA3) \
+    asm volatile("s_nop 15\n\t" RT_EXAM(128, 96, 36, "%[t0]") RT_EXAM(144, 104, 38, "%[t1]") RT_EXAM(160, 112, 40, "%[t2]") RT_EXAM(176, 120, 42, "%[t3]") "s_nop 7\n\t" RT_FOLD("%[anya]", 36) \
+                 : "=&{v[96:101]}"(MA0), "=&{v[104:109]}"(MA1), "=&{v[112:117]}"(MA2), "=&{v[120:125]}"(MA3), [anya] "=&s"(any_a) \
                  : "{v[128:143]}"(X0), "{v[144:159]}"(X1), "{v[160:175]}"(X2), "{v[176:191]}"(X3), [t0] "v"(th0), [t1] "v"(th1), [t2] "v"(th2), [t3] "v"(th3) \
                  : RT_K_CLOBBERS)
 #define RT_EXAMINE_Y() \
-    asm volatile("s_nop 15\n\t" RT_EXAM(192, 64, 44, "%[t0]") RT_EXAM(208, 72, 46, "%[t1]") RT_EXAM(224, 80, 48, "%[t2]") RT_EXAM(240, 88, 50, "%[t3]") "s_nop 7" \
-                 : "=&{v[64:69]}"(MB0), "=&{v[72:77]}"(MB1), "=&{v[80:85]}"(MB2), "=&{v[88:93]}"(MB3) \
+    asm volatile("s_nop 15\n\t" RT_EXAM(192, 64, 44, "%[t0]") RT_EXAM(208, 72, 46, "%[t1]") RT_EXAM(224, 80, 48, "%[t2]") RT_EXAM(240, 88, 50, "%[t3]") "s_nop 7\n\t" RT_FOLD("%[anyb]", 44) \
+                 : "=&{v[64:69]}"(MB0), "=&{v[72:77]}"(MB1), "=&{v[80:85]}"(MB2), "=&{v[88:93]}"(MB3), [anyb] "=&s"(any_b) \
                  : "{v[192:207]}"(Y0), "{v[208:223]}"(Y1), "{v[224:239]}"(Y2), "{v[240:255]}"(Y3), [t0] "v"(th0), [t1] "v"(th1), [t2] "v"(th2), [t3] "v"(th3) \
                  : RT_K_CLOBBERS)
 
@@ -641,21 +662,15 @@ scan_solo_kernel(SceneView sc, WaveBuffers wb, MfView mf, uint32_t bounce, uint3
                 }
                 B0 = Bs[0]; B1 = Bs[1]; B2 = Bs[2]; B3 = Bs[3];
                 th0 = ths[0]; th1 = ths[1]; th2 = ths[2]; th3 = ths[3];
-                uint32_t run_at = ts0;                          // tile of bit 0 of `seg`
-                while (m128_any(seg)) {
-                    // next run of consecutive tiles to scan: [t0, t1)
-                    const uint32_t skip = m128_ctz(seg);
-                    seg = m128_shr(seg, skip);
-                    const uint32_t run = m128_cto(seg);
-                    seg = m128_shr(seg, run);
-                    const uint32_t t0 = run_at + skip, t1 = t0 + run;
-                    run_at = t1;
-                    // prologue: the products of the run's first tile.  The tile rows of a trip are read two trips ahead (by the trip
-                    // statement itself); the four rows behind the chunk's last tile are allocated (and never used).
+                typedef const uint4 __attribute__((address_space(3))) *LdsRow;
+                const uint32_t n_kept = m128_popc(seg);
+                if (n_kept == ts1 - ts0) {
+                    // ---- the whole segment: consecutive tiles [t0, t1), rows read two trips ahead by address increment
+                    const uint32_t t0 = ts0, t1 = ts1;
+                    // prologue: the products of the first tile.  The four rows behind the chunk's last tile are allocated (and never used).
                     const uint4 *row = lds_tiles + (size_t)t0 * 64u + l_lane;
                     auto tile_row = [&]() { const uint4 r = *row; row += 64; return u32x4{r.x, r.y, r.z, r.w}; };
                     u32x4 ap = tile_row(), ay = tile_row(), ax = tile_row(), by, bx;
-                    typedef const uint4 __attribute__((address_space(3))) *LdsRow;
                     uint32_t addr = (uint32_t)(uintptr_t)(LdsRow)row;                       // LDS byte address of tile t0 + 3's row
                     RT_PRODUCTS_X(ap);
                     // steady state: two stages per trip (tile t -> Y beside the examination of tile t-1, tile t+1 -> X beside the
@@ -682,16 +697,63 @@ scan_solo_kernel(SceneView sc, WaveBuffers wb, MfView mf, uint32_t bounce, uint3
                         }
                         ay = by; t += 2u;
                     }
-                    // epilogue: a last single stage if the run's tile count is even, then the examination of the last tile (park()
-                    // finds nothing when there is nothing)
+                    // epilogue: a last single stage if the tile count is even, then the examination of the last tile
                     if (t < t1) {
                         RT_STAGE_Y(ay);
                         if (any_a) park_a(t - 1u);
                         RT_EXAMINE_Y();
-                        park_b(t);
+                        if (any_b) park_b(t);
                     } else {
                         RT_EXAMINE_X();
-                        park_a(t - 1u);
+                        if (any_a) park_a(t - 1u);
+                    }
+                } else {
+                    // ---- a culled segment: the same stream over the LIST of its kept tiles, in storage order; the pipeline fills and
+                    // drains once per segment however the kept tiles are scattered (walking them run by run cost a prologue, an
+                    // epilogue and a parking pass per run: 2.8 steady tiles for a run of one)
+                    unsigned long long cur = seg.lo, nxt = seg.hi;
+                    uint32_t base = ts0;                                                    // tile of bit 0 of `cur`
+                    auto next_tile = [&]() -> uint32_t {                                    // (callers never ask for more tiles than are kept)
+                        if (cur == 0ull) { cur = nxt; nxt = 0ull; base += 64u; }
+                        const uint32_t bit = (uint32_t)__builtin_ctzll(cur);
+                        cur &= ~(1ull << bit);
+                        return base + bit;
+                    };
+                    const uint32_t lds_lane = (uint32_t)(uintptr_t)(LdsRow)(lds_tiles + l_lane);
+                    auto row_addr = [&](uint32_t tile) { return lds_lane + tile * 1024u; };
+                    auto load_row = [&](uint32_t tile) { const uint4 r = lds_tiles[(size_t)tile * 64u + l_lane]; return u32x4{r.x, r.y, r.z, r.w}; };
+                    uint32_t left = n_kept;                                                 // tiles not yet handed to the matrix pipe
+                    uint32_t t_x = next_tile(); --left;                                     // the tile whose products sit in X
+                    u32x4 ap = load_row(t_x), ay, ax, by, bx;
+                    uint32_t t_y = t_x, t_n = t_x;                                          // tiles of the rows in (ay | by), (ax | bx); dummies when none is left
+                    if (left > 0u) t_y = next_tile();
+                    if (left > 1u) t_n = next_tile();
+                    ay = load_row(t_y); ax = load_row(t_n);
+                    RT_PRODUCTS_X(ap);
+                    // a trip: t_y -> Y beside the examination of X (t_x), t_n -> X beside the examination of Y (t_y), and the rows of the
+                    // two tiles behind them on their way; two trips per iteration, so that the row registers swap roles without moves
+#define RT_LIST_TRIP(AY, AX, NY, NX) do { \
+                        left -= 2u; \
+                        const uint32_t u_y = left > 0u ? next_tile() : t_x, u_n = left > 1u ? next_tile() : t_x; \
+                        const uint32_t a_y = row_addr(u_y), a_n = row_addr(u_n); \
+                        RT_TRIP_G(AY, AX, NY, NX, a_y, a_n); \
+                        if (__builtin_expect((any_a | any_b) != 0ull, 0)) { \
+                            if (any_a) park_a(t_x); \
+                            if (any_b) park_b(t_y); \
+                        } \
+                        t_x = t_n; t_y = u_y; t_n = u_n; \
+                    } while (0)
+                    while (left >= 4u) { RT_LIST_TRIP(ay, ax, by, bx); RT_LIST_TRIP(by, bx, ay, ax); }
+                    if (left >= 2u) { RT_LIST_TRIP(ay, ax, by, bx); ay = by; }
+#undef RT_LIST_TRIP
+                    if (left == 1u) {
+                        RT_STAGE_Y(ay);
+                        if (any_a) park_a(t_x);
+                        RT_EXAMINE_Y();
+                        if (any_b) park_b(t_y);
+                    } else {
+                        RT_EXAMINE_X();
+                        if (any_a) park_a(t_x);
                     }
                 }
                 ts0 = ts1;

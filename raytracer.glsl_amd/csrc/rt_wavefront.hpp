@@ -56,6 +56,16 @@ struct WaveBuffers {
     uint32_t *sched;              // kernel 4: per scan launch (bounce) and chunk the next unclaimed item; zeroed with the ray counts at frame start
     uint32_t sched_stride;        //   entries per bounce
     uint32_t *cand_peak;          // max over the frame's scan waves of the pairs a wave wanted to append (host: sizes the regions)
+    // ray binning (kernel 4, option "cull" = 3): shade_kernel leaves the rays of the next bounce in the staging queue `qt` with a bin key
+    // each, sort_scatter_kernel moves them into the next queue in key order, so that the 128 rays of a granule are neighbours in origin
+    // AND direction and packet culling has something to certify on bounces >= 1.  Queue order never shows in a result: the state of
+    // a path travels with its ray, hits merge by visit index, every pixel has one path per frame.
+    RayQueue qt;                  // staging queue (a third queue)
+    uint2 *sort_kr;               // per staging slot: (bin key, rank inside the bin)
+    uint32_t *sort_hist;          // rays per bin -> first slot of the bin (sort_prefix_kernel); 2^sort_bits entries + one block sum per 4096
+    uint32_t sort_bits;           // key = direction bin (8 bits: 16 x 16 octahedral cells in Morton order) << 3 sort_ob | origin cell (Morton, sort_ob bits per axis)
+    uint32_t sort_ob;
+    float sort_lo[3], sort_scale; // origin cell = (o - sort_lo) * sort_scale, clamped to [0, 2^sort_ob)
     float4 *batch_rad;            // frame batching (option "frame_batch"): the paths of B consecutive frames travel through ONE set of launches;
     uint32_t batch_px;            //   a finished path leaves its radiance in batch_rad[frame slot * batch_px + pixel] (the slot rides in the top
                                   //   four bits of the path's pixel word), resolve_batch_kernel folds the slots into the image in frame order
@@ -631,13 +641,43 @@ __global__ void __launch_bounds__(256) intersect_kernel(SceneView sc, WaveBuffer
 
 // One lane per live ray: sphere scan, pick the nearer hit, material response, termination or
 // compaction into the next queue (wave ballot + prefix popcount, one atomicAdd per wave).
-template <bool kCount>
+// kSort: the survivors go to the staging queue with their bin key and their rank inside the bin (one atomic per ray on the bin's
+// counter: the rays of a wave scatter over hundreds of bins); sort_prefix_kernel + sort_scatter_kernel finish the job.
+__device__ __forceinline__ uint32_t spread3(uint32_t x)        // 10 bits -> every third bit
+{
+    x &= 0x3ffu; x = (x | (x << 16)) & 0x30000ffu; x = (x | (x << 8)) & 0x300f00fu; x = (x | (x << 4)) & 0x30c30c3u; x = (x | (x << 2)) & 0x9249249u;
+    return x;
+}
+__device__ __forceinline__ uint32_t spread2(uint32_t x)        // 4 bits -> every second bit
+{
+    x &= 0xfu; x = (x | (x << 2)) & 0x33u; x = (x | (x << 1)) & 0x55u;
+    return x;
+}
+__device__ __forceinline__ uint32_t ray_bin_key(const WaveBuffers &wb, f3 o, f3 d)
+{
+    // direction: octahedral map of d / (|dx| + |dy| + |dz|) to 16 x 16 cells (a zero or non-finite direction lands in some cell: any
+    // key is valid, only the tightness of the granules depends on it)
+    const float l1 = fabsf(d.x) + fabsf(d.y) + fabsf(d.z);
+    const float il = l1 > 0.0f ? 1.0f / l1 : 0.0f;
+    float u = d.x * il, v = d.y * il;
+    if (d.z < 0.0f) { const float uu = (1.0f - fabsf(v)) * (u < 0.0f ? -1.0f : 1.0f), vv = (1.0f - fabsf(u)) * (v < 0.0f ? -1.0f : 1.0f); u = uu; v = vv; }
+    const int iu = min(15, max(0, (int)((u * 0.5f + 0.5f) * 16.0f))), iv = min(15, max(0, (int)((v * 0.5f + 0.5f) * 16.0f)));
+    const uint32_t dir = spread2((uint32_t)iu) | (spread2((uint32_t)iv) << 1);
+    const float top = (float)((1u << wb.sort_ob) - 1u);
+    const uint32_t cx = (uint32_t)fminf(fmaxf((o.x - wb.sort_lo[0]) * wb.sort_scale, 0.0f), top);       // (NaN -> 0)
+    const uint32_t cy = (uint32_t)fminf(fmaxf((o.y - wb.sort_lo[1]) * wb.sort_scale, 0.0f), top);
+    const uint32_t cz = (uint32_t)fminf(fmaxf((o.z - wb.sort_lo[2]) * wb.sort_scale, 0.0f), top);
+    const uint32_t cell = (spread3(cx) | (spread3(cy) << 1) | (spread3(cz) << 2)) & ((1u << (3u * wb.sort_ob)) - 1u);
+    return (dir << (3u * wb.sort_ob)) | cell;
+}
+
+template <bool kCount, bool kSort>
 __global__ void __launch_bounds__(256) shade_kernel(SceneView sc, FrameParams P, ImageView im, WaveBuffers wb,
                                                     uint32_t bounce, uint4 *rng_out, Counters *counters)
 {
     const uint32_t n_rays = wb.counts[bounce];
     const RayQueue qin = (bounce & 1u) ? wb.q[1] : wb.q[0];
-    const RayQueue qout = (bounce & 1u) ? wb.q[0] : wb.q[1];
+    const RayQueue qout = kSort ? wb.qt : ((bounce & 1u) ? wb.q[0] : wb.q[1]);
     const unsigned long long *best_in = (bounce & 1u) ? wb.best[1] : wb.best[0];
     unsigned long long *best_out = (bounce & 1u) ? wb.best[0] : wb.best[1];
     const bool last_bounce = (bounce + 1u >= P.max_bounce);
@@ -686,13 +726,85 @@ __global__ void __launch_bounds__(256) shade_kernel(SceneView sc, FrameParams P,
         for (int w = 0; w < wave; ++w) wave_base += s_cnt[w];
         const uint32_t out_slot = wave_base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
         store_ray(qout, out_slot, s);
-        store_through(best_out + out_slot, kNoHitKey);
+        if (kSort) {
+            const uint32_t key = ray_bin_key(wb, s.o, s.d);
+            const uint32_t rank = atomicAdd(wb.sort_hist + key, 1u);
+            store_through(reinterpret_cast<unsigned long long *>(wb.sort_kr + out_slot), (unsigned long long)key | ((unsigned long long)rank << 32));
+        } else store_through(best_out + out_slot, kNoHitKey);
     }
     __syncthreads();                                                              // s_cnt is rewritten by the next batch
     }
     if (kCount) {
         atomicAdd(&counters->env_lookups, c_env);
         if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&counters->segments, (unsigned long long)n_rays);
+    }
+}
+
+// ---- ray binning: bin counts -> first slots (two launches), then the move staging queue -> next queue.
+// sort_sums_kernel: one block per 4096 bins, their sum.  sort_prefix_kernel: every block adds up the sums of the blocks before it and
+// turns its own 4096 counts into first slots, in place.
+constexpr uint32_t kSortSeg = 4096;
+__global__ void __launch_bounds__(256) sort_sums_kernel(WaveBuffers wb)
+{
+    __shared__ uint32_t part[4];
+    const uint32_t *h = wb.sort_hist + (size_t)blockIdx.x * kSortSeg;
+    const uint4 *h4 = reinterpret_cast<const uint4 *>(h);
+    uint32_t s = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { const uint4 v = h4[k * 256 + threadIdx.x]; s += v.x + v.y + v.z + v.w; }
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if ((threadIdx.x & 63u) == 0u) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) store_through(wb.sort_hist + ((size_t)1u << wb.sort_bits) + blockIdx.x, part[0] + part[1] + part[2] + part[3]);
+}
+__global__ void __launch_bounds__(256) sort_prefix_kernel(WaveBuffers wb)
+{
+    __shared__ uint32_t part[4], wsum[4];
+    const uint32_t *sums = wb.sort_hist + ((size_t)1u << wb.sort_bits);
+    uint32_t before = 0;
+    for (uint32_t i = threadIdx.x; i < blockIdx.x; i += 256u) before += sums[i];
+    for (int off = 32; off > 0; off >>= 1) before += __shfl_xor(before, off);
+    if ((threadIdx.x & 63u) == 0u) part[threadIdx.x >> 6] = before;
+    __syncthreads();
+    before = part[0] + part[1] + part[2] + part[3];
+    // 16 consecutive bins per thread: local sums, wave scan, block scan
+    uint32_t *h = wb.sort_hist + (size_t)blockIdx.x * kSortSeg + threadIdx.x * 16u;
+    uint4 v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = reinterpret_cast<const uint4 *>(h)[k];
+    uint32_t c[16] = {v[0].x, v[0].y, v[0].z, v[0].w, v[1].x, v[1].y, v[1].z, v[1].w, v[2].x, v[2].y, v[2].z, v[2].w, v[3].x, v[3].y, v[3].z, v[3].w};
+    uint32_t tot = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { const uint32_t t = c[k]; c[k] = tot; tot += t; }
+    uint32_t inc = tot;                                       // inclusive scan over the wave
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    for (int off = 1; off < 64; off <<= 1) { const uint32_t t = __shfl_up(inc, off); if (lane >= (uint32_t)off) inc += t; }
+    if (lane == 63u) wsum[wave] = inc;
+    __syncthreads();
+    uint32_t base = before + inc - tot;
+    for (uint32_t w = 0; w < wave; ++w) base += wsum[w];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) store_through(reinterpret_cast<uint4 *>(h) + k, base + c[4 * k], base + c[4 * k + 1], base + c[4 * k + 2], base + c[4 * k + 3]);
+}
+// the rays entering `bounce` (just left in the staging queue by the shade kernel of bounce - 1) to their slots in key order
+__global__ void __launch_bounds__(256) sort_scatter_kernel(WaveBuffers wb, uint32_t bounce)
+{
+    const uint32_t n_rays = wb.counts[bounce];
+    const RayQueue qout = (bounce & 1u) ? wb.q[1] : wb.q[0];
+    unsigned long long *best_out = (bounce & 1u) ? wb.best[1] : wb.best[0];
+    for (uint32_t slot = blockIdx.x * 256u + threadIdx.x; slot < n_rays; slot += gridDim.x * 256u) {
+        const uint2 kr = wb.sort_kr[slot];
+        const uint32_t to = wb.sort_hist[kr.x] + kr.y;
+        const float4 a = wb.qt.a[slot], b = wb.qt.b[slot], c = wb.qt.c[slot];
+        const uint4 g = wb.qt.rng[slot];
+        const uint32_t px = wb.qt.pixel[slot];
+        if (to >= n_rays) continue;                          // (cannot happen: the bins hold exactly the staged rays)
+        store_through(qout.a + to, a.x, a.y, a.z, a.w);
+        store_through(qout.b + to, b.x, b.y, b.z, b.w);
+        store_through(qout.c + to, c.x, c.y, c.z, c.w);
+        store_through(qout.rng + to, g.x, g.y, g.z, g.w);
+        store_through(qout.pixel + to, px);
+        store_through(best_out + to, kNoHitKey);
     }
 }
 

@@ -210,6 +210,9 @@ struct rtgl_context {
     uint2 *d_items = nullptr; size_t items_capacity = 0;          // packet culling: per chunk of a culled scan launch its work items + one count per chunk
     uint32_t *d_sched = nullptr; size_t sched_capacity = 0;       // kernel 4: next unclaimed item per (bounce, chunk)
     uint32_t *d_keep = nullptr; size_t keep_capacity = 0;         // packet culling: (granules of 128 rays) x (quads / 32) words
+    void *d_stage = nullptr; size_t stage_capacity = 0;           // ray binning: the staging queue + (key, rank) per slot
+    uint32_t *d_sort_hist = nullptr; uint32_t sort_bits_alloc = 0;
+    float mesh_lo[3] = {0.0f, 0.0f, 0.0f}, mesh_ext = 0.0f;       // box of the triangles' finite vertices (origin cells of the bin key)
     uint2 *d_cand = nullptr; uint32_t cand_regions = 0, cand_region_pairs = 0, cand_region_target = 0; bool cand_fixed = false;
     bool solo_attr_set = false;              // hipFuncAttributeMaxDynamicSharedMemorySize is per device: raised once per context (= per device binding)
     bool group_explicit = false;             // "mf_group_quads" was set through rtgl_set_option
@@ -233,7 +236,7 @@ struct rtgl_context {
     bool tris_dirty = false, visits_dirty = false;
     FrameParams params{};
     bool have_params = false;
-    int opt_kernel = RTGL_KERNEL_WAVEFRONT_MFMA_SOLO, opt_rng_state = 0, opt_counters = 0, opt_kernel_timing = 0, opt_wf_rays = 4, opt_wf_mode = kLds, opt_wf_chunk = 256, opt_wf_early = 0, opt_wf_packed = 0, opt_mf_chunk_quads = 32, opt_mf_group_quads = 32, opt_cull = 1, opt_scan_waves = 0, opt_scan_dynamic = 0, opt_debug_skip_exact = 0, opt_frame_batch = 1;
+    int opt_kernel = RTGL_KERNEL_WAVEFRONT_MFMA_SOLO, opt_rng_state = 0, opt_counters = 0, opt_kernel_timing = 0, opt_wf_rays = 4, opt_wf_mode = kLds, opt_wf_chunk = 256, opt_wf_early = 0, opt_wf_packed = 0, opt_mf_chunk_quads = 32, opt_mf_group_quads = 32, opt_cull = 3, opt_sort_min_rays = 65536, opt_scan_waves = 0, opt_scan_dynamic = 0, opt_debug_skip_exact = 0, opt_frame_batch = 1;
 };
 
 static int fail(rtgl_context *ctx, int code, const std::string &msg)
@@ -377,7 +380,7 @@ extern "C" void rtgl_destroy(rtgl_context *ctx)
 #endif
     void *ptrs[] = { ctx->d_spheres, ctx->d_materials, ctx->d_vertices, ctx->d_sphere_visits, ctx->d_edges, ctx->d_planes,
                      ctx->d_env, ctx->d_image_own, ctx->d_rng, ctx->d_counters, ctx->d_u8, ctx->d_group_bounds, ctx->d_wave, ctx->d_counts, ctx->d_mf_groups, ctx->d_mf_A, ctx->d_mf_order,
-                     ctx->d_dbg_log, ctx->d_cand, ctx->d_mf_cull, ctx->d_keep, ctx->d_items, ctx->d_sched, ctx->d_edges_s, ctx->d_planes_s, ctx->d_batch_rad };
+                     ctx->d_dbg_log, ctx->d_cand, ctx->d_stage, ctx->d_sort_hist, ctx->d_mf_cull, ctx->d_keep, ctx->d_items, ctx->d_sched, ctx->d_edges_s, ctx->d_planes_s, ctx->d_batch_rad };
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (hipEvent_t e : ctx->kev) (void)hipEventDestroy(e);
     if (ctx->h_counts) (void)hipHostFree(ctx->h_counts);
@@ -667,6 +670,15 @@ static int rebuild_triangles(rtgl_context *ctx)
     if (ctx->d_edges) { HIPCHK(ctx, hipFree(ctx->d_edges)); ctx->d_edges = nullptr; }
     if (ctx->d_planes) { HIPCHK(ctx, hipFree(ctx->d_planes)); ctx->d_planes = nullptr; }
     ctx->n_tri_visits = (uint32_t)visit_tri.size();
+    {
+        float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+        const float *vx = reinterpret_cast<const float *>(ctx->h_vertices.data());
+        for (uint32_t t : visit_tri)
+            for (int k = 0; k < 3; ++k)
+                for (int a = 0; a < 3; ++a) { const float c = vx[(size_t)t * 12 + 4 * k + a]; if (c == c && c > -1.0e30f && c < 1.0e30f) { lo[a] = std::min(lo[a], c); hi[a] = std::max(hi[a], c); } }
+        ctx->mesh_ext = 0.0f;
+        for (int a = 0; a < 3; ++a) { ctx->mesh_lo[a] = lo[a] <= hi[a] ? lo[a] : 0.0f; if (lo[a] <= hi[a]) ctx->mesh_ext = std::max(ctx->mesh_ext, hi[a] - lo[a]); }
+    }
     if (ctx->n_tri_visits) {
         uint32_t *d_visit = nullptr;
         HIPCHK(ctx, hipMalloc((void **)&d_visit, visit_tri.size() * 4));
@@ -779,6 +791,30 @@ static int ensure_wave_buffers(rtgl_context *ctx, uint32_t n0, uint32_t max_boun
             }
             ctx->wb.sched = ctx->d_sched;
         }
+        if (ctx->opt_cull == 3) {                            // ray binning: staging queue (a, b, c, rng: 4 x 16 B, pixel 4 B, key + rank 8 B) and the bin counters
+            if (ctx->stage_capacity < n0) {
+                if (ctx->d_stage) { HIPCHK(ctx, hipFree(ctx->d_stage)); ctx->d_stage = nullptr; }
+                HIPCHK(ctx, hipMalloc(&ctx->d_stage, (size_t)n0 * 76 + 1024));
+                ctx->stage_capacity = n0;
+            }
+            uint8_t *p = (uint8_t *)ctx->d_stage;
+            const size_t cap = ctx->stage_capacity;
+            ctx->wb.qt.a = (float4 *)p; p += cap * 16; ctx->wb.qt.b = (float4 *)p; p += cap * 16; ctx->wb.qt.c = (float4 *)p; p += cap * 16;
+            ctx->wb.qt.rng = (uint4 *)p; p += cap * 16; ctx->wb.sort_kr = (uint2 *)p; p += cap * 8; ctx->wb.qt.pixel = (uint32_t *)p;
+            // origin cells: 16 per axis of the mesh's box (cubes), 32 for more than four million rays
+            ctx->wb.sort_ob = n0 > (4u << 20) ? 5u : 4u;
+            ctx->wb.sort_bits = 8u + 3u * ctx->wb.sort_ob;
+            if (ctx->sort_bits_alloc < ctx->wb.sort_bits) {
+                if (ctx->d_sort_hist) { HIPCHK(ctx, hipFree(ctx->d_sort_hist)); ctx->d_sort_hist = nullptr; }
+                const size_t bins = (size_t)1 << ctx->wb.sort_bits;
+                HIPCHK(ctx, hipMalloc((void **)&ctx->d_sort_hist, (bins + bins / kSortSeg) * sizeof(uint32_t)));
+                ctx->sort_bits_alloc = ctx->wb.sort_bits;
+            }
+            ctx->wb.sort_hist = ctx->d_sort_hist;
+            const float ext = ctx->mesh_ext > 0.0f ? ctx->mesh_ext * 1.02f : 1.0f;
+            for (int a = 0; a < 3; ++a) ctx->wb.sort_lo[a] = ctx->mesh_lo[a] - 0.01f * ext;
+            ctx->wb.sort_scale = (float)(1u << ctx->wb.sort_ob) / ext;
+        }
         ctx->wb.items = reinterpret_cast<uint32_t *>(ctx->d_items); ctx->wb.item_counts = reinterpret_cast<uint32_t *>(ctx->d_items);     // (allocated by the first culled launch)
         ctx->wb.cand = ctx->d_cand;
         ctx->wb.cand_counts = reinterpret_cast<uint32_t *>(ctx->d_cand + (size_t)ctx->cand_regions * ctx->cand_region_pairs);
@@ -865,7 +901,7 @@ static int solo_dynamic(const rtgl_context *ctx)
     return ctx->opt_scan_dynamic ? ctx->opt_scan_dynamic - 1 : (real_quads >= 1024u ? 1 : 0);
 }
 
-static int launch_intersect_solo(rtgl_context *ctx, const SceneView &sc, uint32_t n0, uint32_t bounce)
+static int launch_intersect_solo(rtgl_context *ctx, const SceneView &sc, uint32_t n0, uint32_t bounce, bool binned)
 {
     const uint32_t gq = ctx->mf_group_quads, n_quads = ctx->n_mf_groups * gq;
     const uint32_t real_quads = std::min(n_quads, (ctx->n_tri_visits + (uint32_t)kMfQuadTris - 1) / (uint32_t)kMfQuadTris);
@@ -909,8 +945,9 @@ static int launch_intersect_solo(rtgl_context *ctx, const SceneView &sc, uint32_
         }
         ctx->solo_attr_set = true;
     }
-    // packet culling pays where the 128 rays of a wave are coherent: the camera rays (option "cull": 0 never, 1 bounce 0 (default), 2 every bounce)
-    const int cull = ctx->opt_cull == 2 || (ctx->opt_cull == 1 && bounce == 0);
+    // packet culling pays where the 128 rays of a granule are coherent: the camera rays, and every queue that was binned (option "cull":
+    // 0 never, 1 bounce 0, 2 every bounce as the queues come, 3 (default) bounce 0 and the binned bounces)
+    const int cull = ctx->opt_cull == 2 || (ctx->opt_cull >= 1 && bounce == 0) || (ctx->opt_cull == 3 && binned);
     if (cull) {
         hipLaunchKernelGGL(packet_cull_kernel, dim3(std::max(1u, std::min((est_gran + 3u) / 4u, 8192u))), dim3(256), 0, ctx->stream, ctx->wb, ctx->d_mf_cull, real_quads * (uint32_t)kMfQuadTiles, bounce);
         if (dynamic) {
@@ -968,12 +1005,13 @@ static int launch_wavefront(rtgl_context *ctx, const SceneView &sc, const std::v
         for (uint32_t f = 0; f < B; ++f)
             hipLaunchKernelGGL(generate_rays_kernel, gen_grid, dim3(256), 0, ctx->stream, frames[f], im, ctx->wb, s, n0_frame,
                                ctx->opt_counters ? ctx->d_counters : (Counters *)nullptr, f == 0 ? n_counts : 0u, f * n0_frame, B > 1 ? f << 28 : 0u, f == 0 ? n0 : 0u);
+        bool binned = false;                                 // the queue of the bounce about to be launched was binned
         for (uint32_t b = 0; b < P.max_bounce; ++b) {
             const int key = ctx->opt_wf_mode * 10 + ctx->opt_wf_rays;
             if (ctx->opt_kernel == RTGL_KERNEL_WAVEFRONT_SPLIT || ctx->opt_kernel == RTGL_KERNEL_WAVEFRONT_MFMA_SOLO) {
                 if (sc.n_tri_visits > 0 && ctx->opt_kernel == RTGL_KERNEL_WAVEFRONT_MFMA_SOLO) {
                     kev_mark(ctx);
-                    { const int rc = launch_intersect_solo(ctx, sc, n0, b); if (rc) return rc; }
+                    { const int rc = launch_intersect_solo(ctx, sc, n0, b, binned); if (rc) return rc; }
                     kev_mark(ctx);
                 } else if (sc.n_tri_visits > 0) {
                     kev_mark(ctx);
@@ -991,10 +1029,24 @@ static int launch_wavefront(rtgl_context *ctx, const SceneView &sc, const std::v
                     kev_mark(ctx);
                 }
                 const dim3 shade_grid((estimate_rays(ctx, n0, b) + 255) / 256);
-                if (ctx->opt_counters)
-                    hipLaunchKernelGGL(shade_kernel<true>, shade_grid, dim3(256), 0, ctx->stream, sc, P, im, ctx->wb, b, rng_out, ctx->d_counters);
+                // ray binning: the queue of the next bounce in (direction bin, origin cell) order, where it is long enough to pay for
+                // the three small launches and the extra pass over its rays
+                const uint32_t est_next = estimate_rays(ctx, n0, b + 1u);
+                const bool bin_next = ctx->opt_kernel == RTGL_KERNEL_WAVEFRONT_MFMA_SOLO && ctx->opt_cull == 3 && sc.n_tri_visits > 0 && b + 1u < P.max_bounce
+                                      && est_next >= (uint32_t)ctx->opt_sort_min_rays;
+                if (bin_next) {
+                    const size_t bins = (size_t)1 << ctx->wb.sort_bits;
+                    HIPCHK(ctx, hipMemsetAsync(ctx->wb.sort_hist, 0, bins * sizeof(uint32_t), ctx->stream));
+                    if (ctx->opt_counters) hipLaunchKernelGGL((shade_kernel<true, true>), shade_grid, dim3(256), 0, ctx->stream, sc, P, im, ctx->wb, b, rng_out, ctx->d_counters);
+                    else hipLaunchKernelGGL((shade_kernel<false, true>), shade_grid, dim3(256), 0, ctx->stream, sc, P, im, ctx->wb, b, rng_out, ctx->d_counters);
+                    hipLaunchKernelGGL(sort_sums_kernel, dim3((unsigned)(bins / kSortSeg)), dim3(256), 0, ctx->stream, ctx->wb);
+                    hipLaunchKernelGGL(sort_prefix_kernel, dim3((unsigned)(bins / kSortSeg)), dim3(256), 0, ctx->stream, ctx->wb);
+                    hipLaunchKernelGGL(sort_scatter_kernel, dim3(std::max(1u, std::min((est_next + 255u) / 256u, 16384u))), dim3(256), 0, ctx->stream, ctx->wb, b + 1u);
+                } else if (ctx->opt_counters)
+                    hipLaunchKernelGGL((shade_kernel<true, false>), shade_grid, dim3(256), 0, ctx->stream, sc, P, im, ctx->wb, b, rng_out, ctx->d_counters);
                 else
-                    hipLaunchKernelGGL(shade_kernel<false>, shade_grid, dim3(256), 0, ctx->stream, sc, P, im, ctx->wb, b, rng_out, ctx->d_counters);
+                    hipLaunchKernelGGL((shade_kernel<false, false>), shade_grid, dim3(256), 0, ctx->stream, sc, P, im, ctx->wb, b, rng_out, ctx->d_counters);
+                binned = bin_next;
                 continue;
             }
             kev_mark(ctx);
@@ -1405,8 +1457,11 @@ extern "C" int rtgl_set_option(rtgl_context *ctx, const char *key, int value)
         if (value < 1 || value > (int)kBatchMax) return fail(ctx, RTGL_ERR_INVALID, "frame_batch (consecutive frames traced in one set of launches) must be 1..16");
         ctx->opt_frame_batch = value;
     } else if (!strcmp(key, "cull")) {
-        if (value < 0 || value > 2) return fail(ctx, RTGL_ERR_INVALID, "cull must be 0 (off), 1 (camera rays) or 2 (every bounce)");
+        if (value < 0 || value > 3) return fail(ctx, RTGL_ERR_INVALID, "cull must be 0 (off), 1 (camera rays), 2 (every bounce, queues as they come) or 3 (camera rays + binned bounces)");
         ctx->opt_cull = value;
+    } else if (!strcmp(key, "sort_min_rays")) {
+        if (value < 0) return fail(ctx, RTGL_ERR_INVALID, "sort_min_rays (a bounce's queue is binned when at least this many rays are expected) must be >= 0");
+        ctx->opt_sort_min_rays = value;
     } else if (!strcmp(key, "mf_group_quads")) {
         if (value < 1 || value > (int)kMfMaxGroupQuads || (value & (value - 1))) return fail(ctx, RTGL_ERR_INVALID, "mf_group_quads must be a power of two in [1, 64]");
         if (value != (int)ctx->mf_group_quads) ctx->tris_dirty = true;                         // local origins and A tiles are per group
@@ -1445,6 +1500,7 @@ extern "C" int rtgl_get_option(rtgl_context *ctx, const char *key, int *value)
     else if (!strcmp(key, "mf_chunk_quads")) *value = ctx->opt_mf_chunk_quads;
     else if (!strcmp(key, "mf_group_quads")) *value = (int)ctx->mf_group_quads;
     else if (!strcmp(key, "cull")) *value = ctx->opt_cull;
+    else if (!strcmp(key, "sort_min_rays")) *value = ctx->opt_sort_min_rays;
     else if (!strcmp(key, "scan_waves")) *value = ctx->opt_scan_waves;
     else if (!strcmp(key, "scan_dynamic")) *value = ctx->opt_scan_dynamic;
     else if (!strcmp(key, "frame_batch")) *value = ctx->opt_frame_batch;
@@ -1459,6 +1515,7 @@ extern "C" int rtgl_get_option(rtgl_context *ctx, const char *key, int *value)
         b += (size_t)ctx->n_tri_visits * (sizeof(TriEdges) + sizeof(TriPlane) + 4 + 112) + (size_t)ctx->n_vec4 * 16 + (size_t)ctx->env_faces * ctx->env_w * ctx->env_h * ctx->env_c;
         if (ctx->d_rng) b += (size_t)std::max(ctx->local_rows, 1) * ctx->width * 16;
         b += ctx->batch_capacity * 16;
+        b += ctx->stage_capacity * 76 + (ctx->sort_bits_alloc ? ((size_t)4 << ctx->sort_bits_alloc) : 0);
         *value = (int)((b + (1u << 20) - 1) >> 20);
     }
     else return fail(ctx, RTGL_ERR_INVALID, std::string("unknown option ") + key);

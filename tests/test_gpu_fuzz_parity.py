@@ -2,7 +2,8 @@
 more than one frame are rendered a second time as one batch of frames, option "frame_batch", and must give the same image):
 triangle soups (random positions, sizes from needles to scene-sized, random windings and materials), two meshes, the demo spheres on or
 off, cube map on or off, 1..8 bounces, 1..3 frames, images whose sizes are not multiples of anything, and for the scan: one / two waves
-per SIMD, static / dynamic work distribution, cull off / camera rays / every bounce, chunks of 1..32 quads, groups of 1..64 quads.
+per SIMD, static / dynamic work distribution, cull off / camera rays / every bounce / camera rays + binned queues (with the binning
+forced on queues of any length), chunks of 1..32 quads, groups of 1..64 quads.
 
 In the suite: FUZZ_CASES cases (default 60) from FUZZ_SEED (default 1).  The round-2 campaign was
 `FUZZ_CASES=1500 FUZZ_SEED=7 python -m pytest tests/test_gpu_fuzz_parity.py -m gpu -q`, 4000 cases from seed 11, 8000 from seed 23 and 150 from seed 1: 0 differing cases
@@ -41,7 +42,7 @@ def run_cases(rt, oracle, N, seed):
         p0 = sc.FrameParams(max_bounce=int(rng.integers(1, 9)), use_envmap=int(scene.env is not None), use_dof=int(rng.integers(2)),
                             camera_position=(float(rng.uniform(-5, 5)), float(rng.uniform(-4, 2)), float(rng.uniform(-40, -20))), camera_forward=fwd, camera_right=right,
                             camera_aperture=float(rng.choice([0.001, 0.05, 0.5])), camera_focal_length=float(rng.uniform(8, 45)))
-        opts = dict(kernel=4, scan_waves=int(rng.integers(0, 3)), scan_dynamic=int(rng.integers(0, 3)), cull=int(rng.integers(0, 3)),
+        opts = dict(kernel=4, scan_waves=int(rng.integers(0, 3)), scan_dynamic=int(rng.integers(0, 3)), cull=int(rng.integers(0, 4)), sort_min_rays=int(rng.choice([0, 0, 3000, 65536])),
                     mf_chunk_quads=int(rng.choice([1, 2, 3, 5, 8, 16, 32])), mf_group_quads=int(rng.choice([1, 2, 4, 8, 32, 64])))
         frames = int(rng.integers(1, 4))
         ctx = rt.host.Context(W, H)

@@ -63,6 +63,17 @@ def test_dynamic_work_distribution_matches_reference_shader_output(path, waves, 
     assert (img.view(np.uint32) == expected.view(np.uint32)).all()
 
 
+@pytest.mark.parametrize("dyn", [1, 2])
+@pytest.mark.parametrize("path", CASE_FILES, ids=lambda p: os.path.basename(p)[:-4])
+def test_binned_queues_match_reference_shader_output(path, dyn, rt):
+    """kernel 4 with every queue binned by (direction cell, origin cell) before it is scanned and culled (`cull` = 3 with
+    `sort_min_rays` = 0: the default bins only queues of 65,536 rays and more), static and dynamic work distribution, chunks of two
+    quads -- every golden case.  Queue order must never show in a result."""
+    meta, scene, frames, expected = load_case(path, rt)
+    img = render_case(rt, meta, scene, frames, options=(("kernel", 4), ("cull", 3), ("sort_min_rays", 0), ("scan_dynamic", dyn), ("mf_chunk_quads", 2)))
+    assert (img.view(np.uint32) == expected.view(np.uint32)).all()
+
+
 @pytest.mark.parametrize("path", CASE_FILES, ids=lambda p: os.path.basename(p)[:-4])
 def test_fp32_scan_kernel_matches_reference_shader_output(path, rt):
     """kernel 2: fp32 VALU filter + exact test (the variant without matrix cores) -- every golden case, bit for bit."""

@@ -8,6 +8,8 @@ name = sys.argv[1] if len(sys.argv) > 1 else "C2"
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 cfg = sc.CONFIGS[name]; W, H = cfg["width"], cfg["height"]; scene = cfg["scene"](); base = cfg["params"]()
 ctx = rt.host.Context(W, H, device=0)
+for kv in filter(None, os.environ.get("OPTS", "").split(",")):      # OPTS=cull=1,scan_waves=1 ...
+    k, v = kv.split("="); ctx.set_option(k, int(v))
 ctx.upload_scene(scene)
 if os.environ.get("KERNEL_TIMING"): ctx.set_option("kernel_timing", 1)      # HIP events around every scan launch: total per frame printed below
 g = sc.GlibcRand(0); ps = [base.replace(frames=f, random=g.rand()) for f in range(1, n + 4)]
