@@ -244,10 +244,12 @@ struct alignas(16) MfCull {
     float ax, ay, az, Rc;         // axis of the normals; radius of the centroids about (cx, cy, cz)
     float t1x, t1y, t1z, X;       // tangent frame and the half extents of the normals' gnomonic coordinates
     float t2x, t2y, t2z, Y;
-    float Nmin, shape, hmin, lmax;
-    float E, Pw, inv_len, pad;    // inv_len <= 1 / sqrt(1 + X^2 + Y^2)
+    float Nmin, shape, hmin, lmax;  // lmax = the longest edge: also the E of the reference's rounding bound
+    float Pw, inv_len;            // inv_len <= 1 / sqrt(1 + X^2 + Y^2)
+    float iB, iB2;                // >= 1 / (1 + X^2), 1 / (1 + Y^2)
+    float iB_lo, iB2_lo, pad0, pad1;   // <= the same
 };
-static_assert(sizeof(MfCull) == 96, "six uint4 per tile");
+static_assert(sizeof(MfCull) == 112, "seven uint4 per tile");
 
 __device__ __forceinline__ float wave_sum(float x) { for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off); return x; }
 
@@ -328,9 +330,11 @@ __global__ void __launch_bounds__(64) prepare_cull_kernel(const float4 *__restri
     rec.t2x = t2.x; rec.t2y = t2.y; rec.t2z = t2.z; rec.Y = Y * 1.001f + 1e-5f;
     bad |= !(rec.X < 16.0f) || !(rec.Y < 16.0f);
     rec.Nmin = bad ? 0.0f : Nmin * 0.999f; rec.shape = bad ? 0.0f : shape; rec.hmin = bad ? 0.0f : hmin; rec.lmax = E * 1.001f;
-    rec.E = E * 1.001f; rec.Pw = Pw * 1.001f;
+    rec.Pw = Pw * 1.001f;
     rec.inv_len = 0.9999f / __builtin_sqrtf(1.0f + rec.X * rec.X + rec.Y * rec.Y);
-    rec.pad = 0.0f;
+    rec.iB = 1.0001f / (1.0f + rec.X * rec.X); rec.iB2 = 1.0001f / (1.0f + rec.Y * rec.Y);
+    rec.iB_lo = 0.9999f / (1.0f + rec.X * rec.X); rec.iB2_lo = 0.9999f / (1.0f + rec.Y * rec.Y);
+    rec.pad0 = rec.pad1 = 0.0f;
     out[q] = rec;
 }
 
@@ -347,48 +351,62 @@ __device__ __forceinline__ float mf_max_dot(const MfCull &c, float wa, float w1,
     const bool inside = (wa > 0.0f) && (w1 <= c.X * wa) && (w2 <= c.Y * wa);
     const float num = __builtin_fmaf(c.Y, w2, __builtin_fmaf(c.X, w1, wa));
     const float corner = num * c.inv_len * (num > 0.0f ? 1.0003f : 1.0f);           // (inv_len is a lower bound of 1 / sqrt(1 + X^2 + Y^2))
-    const float A = __builtin_fmaf(c.X, w1, wa), B = __builtin_fmaf(c.X, c.X, 1.0f);
-    const float A2 = __builtin_fmaf(c.Y, w2, wa), B2 = __builtin_fmaf(c.Y, c.Y, 1.0f);
-    // (a stationary point behind the end of its edge: the function still rises at the corner, which has it)
-    const float e1 = (A > 0.0f && w2 * B <= c.Y * A) ? __builtin_amdgcn_sqrtf(__builtin_fmaf(A * A, __builtin_amdgcn_rcpf(B), w2 * w2)) : -__builtin_inff();
-    const float e2 = (A2 > 0.0f && w1 * B2 <= c.X * A2) ? __builtin_amdgcn_sqrtf(__builtin_fmaf(A2 * A2, __builtin_amdgcn_rcpf(B2), w1 * w1)) : -__builtin_inff();
+    const float A = __builtin_fmaf(c.X, w1, wa), A2 = __builtin_fmaf(c.Y, w2, wa);
+    // (a stationary point behind the end of its edge: the function still rises at the corner, which has it.  iB = 1 / (1 + X^2) from
+    // the record, rounded up: w2 (1 + X^2) <= Y A is tested as w2 <= Y A iB' with the rounded-down reciprocal -- erring towards
+    // "behind the end" only moves the bound from the stationary value to the corner's, which differ in second order)
+    const float e1 = (A > 0.0f && w2 <= c.Y * A * c.iB_lo) ? __builtin_amdgcn_sqrtf(__builtin_fmaf(A * A, c.iB, w2 * w2)) : -__builtin_inff();
+    const float e2 = (A2 > 0.0f && w1 <= c.X * A2 * c.iB2_lo) ? __builtin_amdgcn_sqrtf(__builtin_fmaf(A2 * A2, c.iB2, w1 * w1)) : -__builtin_inff();
     const float m = fmaxf(corner, fmaxf(e1, e2));
     return inside ? wn : fminf(m + 1e-4f * wn, wn);
 }
 
-__device__ __forceinline__ bool mf_certified(const MfCull &c, const MfPacket &p)
+// (K) and (A): cheap, and enough for most tiles of a coherent granule; cmin and delta are handed on to nobody: (B) stands on its own
+__device__ __forceinline__ bool mf_certified_ka(const MfCull &c, const MfPacket &p, const f3 g, float L, float nz, float Wn)
 {
-    const f3 g = p.O - mk(c.cx, c.cy, c.cz);                               // O - C
-    const float L = __builtin_amdgcn_sqrtf(dot3(g, g)) * 1.0001f;
-    const float nz = 9.5367431640625e-07f * __builtin_fmaf(c.E, p.On, c.Pw) * 1.01f;      // 2^-20 (E |o| + Pw): the reference's own rounding (mf_margin)
     const f3 a = mk(c.ax, c.ay, c.az), t1 = mk(c.t1x, c.t1y, c.t1z), t2 = mk(c.t2x, c.t2y, c.t2z);
-    // ---- directions against the normals: lower bounds of d^.n^ (all back facing when > 0) and of -d^.n^ (all front facing when > 0)
+    // directions against the normals: lower bounds of d^.n^ (all back facing when > 0) and of -d^.n^ (all front facing when > 0)
     const float Da = dot3(p.D, a), D1 = fabsf(dot3(p.D, t1)), D2 = fabsf(dot3(p.D, t2));
     const float spread = __builtin_fmaf(c.X, D1, c.Y * D2);
     const float num_pos = Da - spread, num_neg = -Da - spread;
     const float lo_pos = (num_pos > 0.0f ? num_pos * c.inv_len : num_pos) - p.sigma - 1e-5f;
     const float lo_neg = (num_neg > 0.0f ? num_neg * c.inv_len : num_neg) - p.sigma - 1e-5f;
-    const bool usable = c.Nmin > 0.0f;
     // (K) every triangle back facing for every ray
     const bool cert_k = (lo_pos > 0.0f) && ((c.Nmin * lo_pos) * 0.3333f * 0.99f >= nz);
     // (A) the lines miss the tile's sphere by delta, and |d^.n^| >= cmin
-    const f3 W = cross3(p.D, g);                                          // moment of the axis about the tile's centre
-    const float Wn = __builtin_amdgcn_sqrtf(dot3(W, W));
     const float delta = (Wn * 0.9999f - L * p.sigma) - (p.ro + c.R) - 1e-5f * (L + p.ro + c.R);
     const float cmin = fmaxf(lo_pos, lo_neg);
     const float lhs_a = (c.Nmin * cmin) * fminf(0.3333f, delta * c.shape) * 0.99f;
     const bool cert_a = (delta > 0.0f) && (cmin > 0.0f) && (lhs_a > 0.0f) && (lhs_a >= nz);
-    // (B) the moment form
+    return cert_k || cert_a;
+}
+
+// (B) the moment form
+__device__ __forceinline__ bool mf_certified_b(const MfCull &c, const MfPacket &p, const f3 W, float L, float nz, float Wn)
+{
+    const f3 a = mk(c.ax, c.ay, c.az), t1 = mk(c.t1x, c.t1y, c.t1z), t2 = mk(c.t2x, c.t2y, c.t2z);
     const float slack = (p.ro + c.Rc) + L * p.sigma + 1e-5f * (L + p.ro + c.Rc);
     const float Wa = dot3(W, a), W1 = fabsf(dot3(W, t1)), W2 = fabsf(dot3(W, t2));
-    const float Wn_up = Wn * 1.0001f;
-    const float M = fmaxf(mf_max_dot(c, Wa, W1, W2, Wn_up), mf_max_dot(c, -Wa, W1, W2, Wn_up));
-    const float Wn_lo = Wn * 0.9999f;
+    const float Wn_up = Wn * 1.0001f, Wn_lo = Wn * 0.9999f;
+    // M >= max |W.n^|: the rectangle's side of the sign of W.a in full; the other side's numerator is at most X W1 + Y W2 - |W.a| and
+    // its denominator at least 1
+    const float far_side = fmaxf(0.0f, __builtin_fmaf(c.Y, W2, __builtin_fmaf(c.X, W1, -fabsf(Wa)))) * 1.0001f;
+    const float M = fmaxf(mf_max_dot(c, fabsf(Wa), W1, W2, Wn_up), far_side);
     const float wp = __builtin_amdgcn_sqrtf(fmaxf(0.0f, __builtin_fmaf(Wn_lo, Wn_lo, -(M * M)))) * 0.9999f - slack;
     const float dist = Wn_lo - slack;
     const float lhs_b = (c.hmin * wp) * (0.5f - (c.lmax * 0.33334f) * __builtin_amdgcn_rcpf(dist) * 1.0001f) * 0.99f;
-    const bool cert_b = (wp > 0.0f) && (dist > 1.3334f * c.lmax) && (M < Wn_lo) && (lhs_b > 0.0f) && (lhs_b >= nz);
-    return usable && (cert_k || cert_a || cert_b);                        // any NaN: false
+    return (wp > 0.0f) && (dist > 1.3334f * c.lmax) && (M < Wn_lo) && (lhs_b > 0.0f) && (lhs_b >= nz);
+}
+
+// all three for one lane (the culling kernel evaluates (B) only where a wave has a lane that (K) and (A) left open)
+__device__ __forceinline__ bool mf_certified(const MfCull &c, const MfPacket &p)
+{
+    const f3 g = p.O - mk(c.cx, c.cy, c.cz);                               // O - C
+    const float L = __builtin_amdgcn_sqrtf(dot3(g, g)) * 1.0001f;
+    const float nz = 9.5367431640625e-07f * __builtin_fmaf(c.lmax, p.On, c.Pw) * 1.01f;   // 2^-20 (E |o| + Pw): the reference's own rounding (mf_margin); lmax = E
+    const f3 W = cross3(p.D, g);                                          // moment of the axis about the tile's centre
+    const float Wn = __builtin_amdgcn_sqrtf(dot3(W, W));
+    return (c.Nmin > 0.0f) && (mf_certified_ka(c, p, g, L, nz, Wn) || mf_certified_b(c, p, W, L, nz, Wn));       // any NaN: false
 }
 
 }  // namespace rt

@@ -236,7 +236,7 @@ struct rtgl_context {
     bool tris_dirty = false, visits_dirty = false;
     FrameParams params{};
     bool have_params = false;
-    int opt_kernel = RTGL_KERNEL_WAVEFRONT_MFMA_SOLO, opt_rng_state = 0, opt_counters = 0, opt_kernel_timing = 0, opt_wf_rays = 4, opt_wf_mode = kLds, opt_wf_chunk = 256, opt_wf_early = 0, opt_wf_packed = 0, opt_mf_chunk_quads = 32, opt_mf_group_quads = 32, opt_cull = 3, opt_sort_min_rays = 65536, opt_scan_waves = 0, opt_scan_dynamic = 0, opt_debug_skip_exact = 0, opt_frame_batch = 1;
+    int opt_kernel = RTGL_KERNEL_WAVEFRONT_MFMA_SOLO, opt_rng_state = 0, opt_counters = 0, opt_kernel_timing = 0, opt_wf_rays = 4, opt_wf_mode = kLds, opt_wf_chunk = 256, opt_wf_early = 0, opt_wf_packed = 0, opt_mf_chunk_quads = 32, opt_mf_group_quads = 32, opt_cull = 3, opt_sort_min_rays = 131072, opt_scan_waves = 0, opt_scan_dynamic = 0, opt_debug_skip_exact = 0, opt_frame_batch = 1;
 };
 
 static int fail(rtgl_context *ctx, int code, const std::string &msg)

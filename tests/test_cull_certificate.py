@@ -111,10 +111,11 @@ def max_dot(rec, wa, w1, w2, wn):
         return wn
     num = wa + X * w1 + Y * w2
     corner = num * rec["inv_len"] * (f32(1.0003) if num > 0 else f32(1))
-    A, B = wa + X * w1, f32(1) + X * X
-    A2, B2 = wa + Y * w2, f32(1) + Y * Y
-    e1 = np.sqrt(A * A / B + w2 * w2) if (A > 0 and w2 * B <= Y * A) else -np.inf
-    e2 = np.sqrt(A2 * A2 / B2 + w1 * w1) if (A2 > 0 and w1 * B2 <= X * A2) else -np.inf
+    A, A2 = wa + X * w1, wa + Y * w2
+    iB, iB2 = f32(1.0001) / (f32(1) + X * X), f32(1.0001) / (f32(1) + Y * Y)
+    iB_lo, iB2_lo = f32(0.9999) / (f32(1) + X * X), f32(0.9999) / (f32(1) + Y * Y)
+    e1 = np.sqrt(A * A * iB + w2 * w2) if (A > 0 and w2 <= Y * A * iB_lo) else -np.inf
+    e2 = np.sqrt(A2 * A2 * iB2 + w1 * w1) if (A2 > 0 and w1 <= X * A2 * iB2_lo) else -np.inf
     return min(max(corner, e1, e2) + f32(1e-4) * wn, wn)
 
 
@@ -124,7 +125,7 @@ def certificates(rec, pk):
         return False, False, False
     g = (pk["O"] - rec["c"]).astype(f32)
     L = np.sqrt(dot3(g, g)) * f32(1.0001)
-    nz = f32(9.5367431640625e-07) * (rec["E"] * pk["On"] + rec["Pw"]) * f32(1.01)
+    nz = f32(9.5367431640625e-07) * (rec["lmax"] * pk["On"] + rec["Pw"]) * f32(1.01)
     D, a, t1, t2 = pk["D"], rec["a"], rec["t1"], rec["t2"]
     Da, D1, D2 = dot3(D, a), abs(dot3(D, t1)), abs(dot3(D, t2))
     spread = rec["X"] * D1 + rec["Y"] * D2
@@ -141,7 +142,8 @@ def certificates(rec, pk):
     slack = (pk["ro"] + rec["Rc"]) + L * pk["sigma"] + f32(1e-5) * (L + pk["ro"] + rec["Rc"])
     Wa, W1, W2 = dot3(W, a), abs(dot3(W, t1)), abs(dot3(W, t2))
     Wn_up, Wn_lo = Wn * f32(1.0001), Wn * f32(0.9999)
-    M = max(max_dot(rec, Wa, W1, W2, Wn_up), max_dot(rec, -Wa, W1, W2, Wn_up))
+    far_side = max(f32(0), rec["X"] * W1 + rec["Y"] * W2 - abs(Wa)) * f32(1.0001)
+    M = max(max_dot(rec, abs(Wa), W1, W2, Wn_up), far_side)
     wp = np.sqrt(max(f32(0), Wn_lo * Wn_lo - M * M)) * f32(0.9999) - slack
     dist = Wn_lo - slack
     with np.errstate(divide="ignore", invalid="ignore"):

@@ -67,7 +67,7 @@ def test_dynamic_work_distribution_matches_reference_shader_output(path, waves, 
 @pytest.mark.parametrize("path", CASE_FILES, ids=lambda p: os.path.basename(p)[:-4])
 def test_binned_queues_match_reference_shader_output(path, dyn, rt):
     """kernel 4 with every queue binned by (direction cell, origin cell) before it is scanned and culled (`cull` = 3 with
-    `sort_min_rays` = 0: the default bins only queues of 65,536 rays and more), static and dynamic work distribution, chunks of two
+    `sort_min_rays` = 0: the default bins only queues of 131,072 rays and more), static and dynamic work distribution, chunks of two
     quads -- every golden case.  Queue order must never show in a result."""
     meta, scene, frames, expected = load_case(path, rt)
     img = render_case(rt, meta, scene, frames, options=(("kernel", 4), ("cull", 3), ("sort_min_rays", 0), ("scan_dynamic", dyn), ("mf_chunk_quads", 2)))
