@@ -65,6 +65,22 @@ def cpu_baseline(rt, scene, params, width, height, budget_rows=256):
     }
 
 
+def relaunch_command(argv, n_gpus, port=None):
+    """`python bench.py --gpus N ...` typed without a launcher: the command that starts the N ranks (one per GPU, RCCL), built before
+    anything touches the GPU.  The parent only relays the child's output and return code."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port if port is not None else 29400 + os.getpid() % 2000), os.path.abspath(__file__)]
+    return cmd + list(argv)
+
+
+def relaunch(argv, n_gpus):
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    proc = subprocess.run(relaunch_command(argv, n_gpus), env=env)
+    return proc.returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -80,7 +96,8 @@ def main():
     ap.add_argument("--debug-skip-exact", type=int, default=None, help="diagnostic (wrong image): 1 drops the broad-phase survivors, 2 lets nothing survive")
     ap.add_argument("--mf-chunk-quads", type=int, default=None, help="kernel 4: 40-triangle quads per LDS-resident chunk (1..32)")
     ap.add_argument("--mf-group-quads", type=int, default=None, help="kernel 4: quads sharing one local origin (1, 2, 4 .. 64)")
-    ap.add_argument("--cull", type=int, default=None, help="kernel 4 packet culling: 0 off, 1 camera-ray bounce (default), 2 every bounce")
+    ap.add_argument("--cull", type=int, default=None, help="kernel 4 packet culling: 0 off, 1 camera-ray bounce, 2 every bounce (queues as they come), 3 camera rays + binned queues (default)")
+    ap.add_argument("--sort-min-rays", type=int, default=None, help="kernel 4, cull 3: a bounce's queue is binned when at least this many rays are expected")
     ap.add_argument("--debug-bounces", type=int, default=None, help="diagnostic: override the bounce limit of the configuration (not the named workload)")
     ap.add_argument("--strip-rows", type=int, default=8, help="rows per interleaved strip (multiple of 8); 8 balances the ranks to +-3%% at N = 8, 16 to +-6%%")
     ap.add_argument("--timing-period", type=int, default=None, help="frames between kernel-timed frames (default: 4)")
@@ -94,6 +111,9 @@ def main():
     ap.add_argument("--cpu-rows", type=int, default=1080, help="rows of the frame the CPU baseline renders (8-row strips, uniformly strided): 1080 = the whole C2 frame, ~10 s on 16 threads")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:      # typed without a launcher: start the ranks as a child job (nothing has touched the GPU yet)
+        raise SystemExit(relaunch(sys.argv[1:], args.gpus))
+
     import torch
     import raytracer_glsl_amd as rt
     sc = rt.scenes
@@ -102,16 +122,24 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
         raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # TEST ONLY (tests/test_gpu_bench_launcher.py, a one-GPU box): RTGL_BENCH_SHARED_DEVICE=1 maps every rank to device 0.  RCCL refuses two
+    # ranks on one device, so that mapping exchanges the tile buffers through the host with gloo; everything else -- the launcher, the rank
+    # plumbing, the strips, the barriers, the JSON line -- is the code the driver's multi-GPU run takes.
+    shared_device = os.environ.get("RTGL_BENCH_SHARED_DEVICE") == "1"
+    dev_index = 0 if shared_device else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    backend = "none"
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)   # nccl == RCCL on ROCm
+        backend = "gloo" if shared_device else "nccl"
+        if shared_device:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)   # nccl == RCCL on ROCm
 
     cfg = sc.CONFIGS[args.config]
     W, H = cfg["width"], cfg["height"]
@@ -120,15 +148,16 @@ def main():
     if args.debug_bounces is not None:
         base.max_bounce = args.debug_bounces
 
-    ctx = rt.host.Context(W, H, device=local_rank, rank=rank, world=world, strip_rows=args.strip_rows)
+    ctx = rt.host.Context(W, H, device=dev_index, rank=rank, world=world, strip_rows=args.strip_rows)
     ctx.upload_scene(scene)
     for key, val in (("kernel", args.kernel), ("wf_rays", args.wf_rays), ("wf_mode", args.wf_mode), ("wf_chunk", args.wf_chunk), ("wf_early", args.wf_early), ("wf_packed", args.wf_packed),
-                     ("mf_chunk_quads", args.mf_chunk_quads), ("cull", args.cull), ("mf_group_quads", args.mf_group_quads), ("debug_skip_exact", args.debug_skip_exact)):
+                     ("mf_chunk_quads", args.mf_chunk_quads), ("cull", args.cull), ("sort_min_rays", args.sort_min_rays), ("mf_group_quads", args.mf_group_quads), ("debug_skip_exact", args.debug_skip_exact)):
         if val is not None:
             ctx.set_option(key, val)
-    gat = rt.tiling.FrameGatherer(W, H, rank, world, dev, args.strip_rows)
-    ctx.bind_device_image(gat.local.data_ptr())          # render straight into the buffer the gather sends
-    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    gat = rt.tiling.FrameGatherer(W, H, rank, world, torch.device("cpu") if shared_device else dev, args.strip_rows)
+    if not shared_device:
+        ctx.bind_device_image(gat.local.data_ptr())      # render straight into the buffer the gather sends
+        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     # HIP events around every launch of the dominant kernel, in every 4th frame: each event pair is ~3 us of launch gap, 16 pairs per frame
     # are 1.4 % of a C2 frame at N = 1 and 7 % of a rank's frame at N = 8
     if args.frame_batch > 1:
@@ -151,7 +180,11 @@ def main():
         ctx.render(p, sync=False)
         submitted[0] += 1
         if submitted[0] % batch_now[0] == 0:   # (every frame unless --frame-batch: then when the batch has been submitted)
-            gat.gather(overlap=world > 1)  # N > 1: snapshot + asynchronous RCCL gather, overlapped with the next frame's render
+            if shared_device:              # (test mapping: tile buffer through the host, blocking gloo gather)
+                gat.local[: ctx.local_rows] = torch.from_numpy(ctx.read_image())
+                gat.gather()
+            else:
+                gat.gather(overlap=world > 1)  # N > 1: snapshot + asynchronous RCCL gather, overlapped with the next frame's render
 
     def barrier():
         ctx.synchronize()                  # (submits what a batching context still holds back)
@@ -184,14 +217,14 @@ def main():
         timed_frames = t["frames"]
         assert timed_frames == (args.steps + timing_period - 1) // timing_period
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if shared_device else dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
     # A second region, reported beside `value`, never as it: the same workload with 2 x N (at most 16) frames traced per set of launches (option
     # "frame_batch", DESIGN.md 7: bit-identical image; the image -- and at N > 1 the gather -- follows every batch instead of every frame).
     batched = None
-    if args.frame_batch == 1 and (args.batched_extra == "on" or (args.batched_extra == "auto" and world > 1)) and args.steps >= 8 and not args.sync_each_frame:
+    if args.frame_batch == 1 and (args.batched_extra == "on" or (args.batched_extra == "auto" and world > 1)) and args.steps >= 8 and not args.sync_each_frame and not shared_device:
         try:                                               # (whatever happens here must not cost the line its `value`)
             B = min(2 * world, 16)                         # a rank then launches what two whole frames are to a single GPU
             kb = args.steps // B * B
@@ -233,7 +266,7 @@ def main():
     ctx.set_option("counters", 0)
     if world > 1:
         ct = torch.tensor([cnt["segments"], cnt["triangle_tests"], cnt["env_lookups"], cnt["paths"], cnt["candidates"], cnt["culled_tests"]],
-                          dtype=torch.float64, device=dev)
+                          dtype=torch.float64, device="cpu" if shared_device else dev)
         dist.all_reduce(ct, op=dist.ReduceOp.SUM)
         cnt = dict(segments=int(ct[0]), triangle_tests=int(ct[1]), env_lookups=int(ct[2]), paths=int(ct[3]), candidates=int(ct[4]), culled_tests=int(ct[5]))
 
@@ -271,21 +304,29 @@ def main():
             n_simd, clk = 1024.0, 2.4e9
             products_per_launch = cnt["triangle_tests"] * share / launches_per_frame / 320.0
             executed_per_launch = (cnt["triangle_tests"] - cnt["culled_tests"]) * share / launches_per_frame / 320.0   # packet culling skips the rest
-            mfma_tflops = products_per_launch * 32768.0 / avg_launch_s / 1e12
-            roof = {"bound": "mfma", "achieved": mfma_tflops, "peak": BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": mfma_tflops / BF16_DENSE_PEAK_TFLOPS,
+            executed_tflops = executed_per_launch * 32768.0 / avg_launch_s / 1e12
+            effective_tflops = products_per_launch * 32768.0 / avg_launch_s / 1e12
+            # matrix-pipe occupancy and shader clock of the same command under rocprofv3 / in the stamps build: committed profile, not this run
+            derived = None
+            df = os.path.join(ROOT, "profiles", "pmc_derived.json")        # tools/diagnostics/summarize_profile.py
+            if os.path.exists(df) and world == 1:
+                derived = json.load(open(df)).get(args.config)
+            roof = {"bound": "mfma", "achieved": executed_tflops, "peak": BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": executed_tflops / BF16_DENSE_PEAK_TFLOPS,
                     "traffic": traffic, "traffic_source": traffic_src, "kernel": kname, "launches_per_frame": launches_per_frame, "avg_launch_ms": avg_launch_s * 1e3,
-                    "products_per_launch": products_per_launch, "cycles_per_product": n_simd * clk * avg_launch_s / max(products_per_launch, 1.0),
-                    "frac_of_mfma_issue_peak": products_per_launch / avg_launch_s / (n_simd * clk / 32.0),
+                    "definition": "achieved = matrix flops of the v_mfma_f32_32x32x16_bf16 instructions actually ISSUED per launch (32,768 flop per product of 10 triangles x 32 rays; "
+                                  "tests a granule skips because all of its rays are certified rejections are not counted) / average launch duration",
+                    "products_per_launch": executed_per_launch, "culled_fraction": cnt["culled_tests"] / max(cnt["triangle_tests"], 1),
+                    "cycles_per_product": n_simd * clk * avg_launch_s / max(executed_per_launch, 1.0),
+                    "frac_of_mfma_issue_peak": executed_per_launch / avg_launch_s / (n_simd * clk / 32.0),
                     "issue_floor_cycles_per_product": 44.0,
-                    "executed": {"products_per_launch": executed_per_launch, "culled_fraction": cnt["culled_tests"] / max(cnt["triangle_tests"], 1),
-                                 "tflops": executed_per_launch * 32768.0 / avg_launch_s / 1e12,
-                                 "cycles_per_product": n_simd * clk * avg_launch_s / max(executed_per_launch, 1.0),
-                                 "frac_of_mfma_issue_peak": executed_per_launch / avg_launch_s / (n_simd * clk / 32.0),
-                                 "note": "matrix instructions actually issued: the algorithmic figures above count every ray x triangle test the reference "
-                                         "performs, including those a wave skips because all of its rays are certified rejections (packet culling)"},
+                    "mfma_busy": derived,
+                    "effective": {"products_per_launch": products_per_launch, "tflops": effective_tflops, "frac": effective_tflops / BF16_DENSE_PEAK_TFLOPS,
+                                  "cycles_per_product": n_simd * clk * avg_launch_s / max(products_per_launch, 1.0),
+                                  "note": "algorithmic equivalent, NOT an achieved-of-peak figure: every ray x triangle test the reference performs priced as if it had been "
+                                          "multiplied, including the tests packet culling never issues (this can exceed 1)"},
                     "note": "dominant kernel launch = packet culling (culled bounces) + scan + narrow phase, timed together.  bound = matrix/vector issue of a SIMD: 32 cycles of matrix pipe per product; 44 cycles of issue "
                             "(MFMA 8 + 9 VALU x 4) measured for the bare instruction stream of one wave, 33 with two waves per SIMD, 38-40 with the loop's scalar instructions (tools/scan_stage_rate.hip); cycles are counted at the "
-                            "nominal 2.4 GHz, the chip runs the two-wave loop at ~1.7 GHz",
+                            "nominal 2.4 GHz (the clock the chip holds in this loop: mfma_busy.in_kernel_clock_ghz).  SURVEY 8(d3)'s fp32-VALU and HBM rows are superseded for this kernel (DESIGN.md 6)",
                     "hbm": hbm}
             compute = {"pipe": "bf16 MFMA broad phase + fp32 VALU examination (one issue port per SIMD)", "algorithmic_tflops": tflops, "flop_per_test": 36,
                        "gtests_per_s": gtests, "scan_share_of_frame": scan_ms / max(frame_ms, 1e-9)}
@@ -298,11 +339,11 @@ def main():
             "metric": "Mpaths/s at 1920x1080, 8 bounces, 10k tris" if args.config == "C2" else f"Mpaths/s ({args.config})",
             "value": paths / dt / 1e6, "unit": "Mpaths/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32", "data": "synthetic", "rccl_ranks": (dist.get_world_size() if world > 1 else 1), "collective_backend": backend,
             "config": {"workload": f"{args.config}: {W}x{H}, {base.max_bounce} bounces, {scene.n_triangles} triangles + "
                                    f"{scene.spheres.shape[0]} spheres, cube map {scene.env.shape[1] if scene.env is not None else 0}^2, "
                                    f"1 spp/frame progressive, dof={base.use_dof}",
-                       "parallelism": f"{world} GPU(s), {args.strip_rows}-row strips interleaved, gather to rank 0 every " + ("frame" if args.frame_batch == 1 else f"batch of {args.frame_batch} frames") + (" (asynchronous, overlapped with the next frame)" if world > 1 else ""),
+                       "parallelism": ("TEST MAPPING (RTGL_BENCH_SHARED_DEVICE=1): every rank on device 0, tile buffers through the host, gloo -- not a multi-GPU result; " if shared_device else "") + f"{world} GPU(s), {args.strip_rows}-row strips interleaved, gather to rank 0 every " + ("frame" if args.frame_batch == 1 else f"batch of {args.frame_batch} frames") + (" (asynchronous, overlapped with the next frame)" if world > 1 else ""),
                        "frame_batch": args.frame_batch,
                        "kernel": ctx.get_option("kernel_in_use"), "wf_rays": ctx.get_option("wf_rays"), "wf_mode": ctx.get_option("wf_mode"), "wf_chunk": ctx.get_option("wf_chunk"), "wf_early": ctx.get_option("wf_early"), "wf_packed": ctx.get_option("wf_packed"),
                        "mf_sets": ctx.get_option("mf_sets"), "mf_group_quads": ctx.get_option("mf_group_quads"), "mf_chunk_quads": ctx.get_option("mf_chunk_quads")},

@@ -103,7 +103,8 @@ int rtgl_create_tiled(rtgl_context **out, int width, int height, int device, int
  * when all have submitted; the environment variable RTGL_AMD_MULTI_THREADS=0, read here, keeps submission on the caller's thread. */
 int rtgl_create_multi(rtgl_context **out, int width, int height, const int *devices, int n_devices, int strip_rows);
 int rtgl_device_count(const rtgl_context *ctx);   /* 1 for a single-device context */
-int rtgl_gather_tiles(rtgl_context *ctx);         /* enqueue the gather on devices[0]'s stream (no-op for a single-device context) */
+int rtgl_gather_tiles(rtgl_context *ctx);         /* enqueue the gather on devices[0]'s stream (no-op for a single-device context); every device's
+                                                    * stream then waits for the copies before its next frame (the tiles are being read) */
 
 void rtgl_destroy(rtgl_context *ctx);
 const char *rtgl_last_error(const rtgl_context *ctx); /* ctx may be NULL: error of the last failed create */
@@ -140,9 +141,16 @@ int rtgl_local_rows(const rtgl_context *ctx);      /* rows held by this context 
 int rtgl_local_row_to_global(const rtgl_context *ctx, int local_row);
 
 /* -- plumbing for callers that own device memory / streams (PyTorch, RCCL) */
-void *rtgl_device_image(rtgl_context *ctx);                 /* device pointer of the local RGBA32F buffer */
+void *rtgl_device_image(rtgl_context *ctx);                 /* device pointer of the local RGBA32F buffer (NULL: see rtgl_last_error) */
 int rtgl_bind_device_image(rtgl_context *ctx, void *dptr);  /* render into caller-owned device memory (local_rows*width*16 B) */
-int rtgl_set_stream(rtgl_context *ctx, void *hip_stream);   /* hipStream_t; NULL restores the context's own stream */
+/* hipStream_t; NULL restores the context's own stream.  All contexts of a process on one device submit to ONE stream of the library's by
+ * default, so that their pipelines never run concurrently (several path-tracing pipelines at once on one MI355X have produced wrong
+ * frames: DESIGN.md 5.2).  rtgl_set_stream therefore FAILS with RTGL_ERR_STATE when another live context of the process renders on a
+ * different stream of the same device; bind the same stream to all of them, or set RTGL_AMD_ALLOW_CONCURRENT_PIPELINES=1 and take the
+ * ordering over.  The library cannot see other PROCESSES on the device: do not run two path-tracing processes on one GPU at the same time.
+ * With "frame_batch" > 1, synchronising the bound stream is NOT enough to know that a frame has been submitted: only rtgl_synchronize and
+ * the read-out calls submit the frames a batching context holds back. */
+int rtgl_set_stream(rtgl_context *ctx, void *hip_stream);
 
 /* -- diagnostics */
 int rtgl_get_counters(rtgl_context *ctx, rtgl_counters *out);  /* synchronises */
@@ -150,8 +158,11 @@ int rtgl_read_rng_state(rtgl_context *ctx, uint32_t *xyzw);    /* per local pixe
 /* keys: "kernel" (enum above), "wf_rays" (rays per lane 1/2/4/8), "wf_mode" (0 scalar-fed, 1 LDS tiles),
  * "wf_chunk" (triangles per work item of the split intersect kernel, multiple of 64), "wf_early" (leading bounces
  * that use the wave-level edge short circuit), "wf_packed" (v_pk_fma_f32 ray pairs on/off), "mf_chunk_quads" (kernel 4: 40-triangle quads
- * per work item = per block's LDS-resident chunk, 1..32), "scan_waves" (waves per SIMD of the kernel-4 scan: 0 default (= 2), 1, 2), "scan_dynamic" (work distribution of the kernel-4 scan: 0 chosen by the mesh (default), 1 static, 2 dynamic), "cull" (packet culling of whole quads per wave:
- * 0 off, 1 on the camera-ray bounce (default), 2 on every bounce), "mf_group_quads" (quads
+ * per work item = per block's LDS-resident chunk, 1..32), "scan_waves" (waves per SIMD of the kernel-4 scan: 0 default (= 2), 1, 2), "scan_dynamic" (work distribution of the kernel-4 scan: 0 chosen by the mesh (default), 1 static, 2 dynamic), "cull" (packet culling: a granule of 128 rays skips the tiles
+ * of 10 triangles for which every one of its rays is certified to be rejected by the reference's own test: 0 off, 1 on the camera-ray
+ * bounce, 2 on every bounce with the queues as they come, 3 (default) on the camera-ray bounce and on every bounce whose queue was BINNED
+ * -- moved into (direction cell, origin cell) order between the bounces, which is what makes its granules coherent), "sort_min_rays"
+ * (cull 3: a bounce's queue is binned when at least this many rays are expected, default 131072), "mf_group_quads" (quads
  * sharing one local origin: a power of two up to 64; changing it rebuilds the broad-phase data at the next frame),
  * "rng_state", "counters", "kernel_timing" (0 off; N > 0: every N-th frame since the last rtgl_timing_reset carries HIP
  * event pairs around its dominant-kernel launches), "frame_batch" (1 (default) .. 16, also RTGL_AMD_FRAME_BATCH: with B > 1 rtgl_render_frame
@@ -159,7 +170,8 @@ int rtgl_read_rng_state(rtgl_context *ctx, uint32_t *xyzw);    /* per local pixe
  * frame order -- bit-identical to frame-by-frame, B times the rays per launch (what a rank of a multi-GPU run lacks).  Every other entry
  * point submits the waiting frames first, so the image a caller reads is always complete; frames that differ in samples, bounce limit,
  * environment switch or background close a batch early; with "counters", "rng_state" or "kernel_timing" on, with more than one sample
- * per frame and for scenes without triangles frames are rendered one by one; rtgl_destroy drops frames that are still waiting) */
+ * per frame and for scenes without triangles frames are rendered one by one; rtgl_destroy submits frames that are still waiting;
+ * rtgl_device_image returns NULL when that submission fails) */
 int rtgl_set_option(rtgl_context *ctx, const char *key, int value);
 int rtgl_get_option(rtgl_context *ctx, const char *key, int *value);   /* also "kernel_in_use": the variant the last frame ran */
 /* elapsed GPU milliseconds of the last rtgl_render_frame (HIP events on the context's stream) */

@@ -225,6 +225,7 @@ struct rtgl_context {
     // and `parts` are the per-device tiled contexts that render the strips; every entry point fans out to them
     std::vector<rtgl_context *> parts;
     std::vector<hipEvent_t> part_done;
+    hipEvent_t gather_done = nullptr;                     // recorded behind the gather's copies; every part waits for it before its next frame
     std::vector<std::unique_ptr<PartWorker>> workers;     // one per part when there is more than one (RTGL_AMD_MULTI_THREADS=0: none, the caller's thread submits)
     bool gathered = false, peer_copy = true;
 
@@ -288,6 +289,32 @@ static hipError_t acquire_device_stream(int device, hipStream_t *out, bool *shar
     *out = it->second.first; *shared = true;
     return hipSuccess;
 }
+// Which stream every live context of this process submits to, per device: rtgl_set_stream refuses a binding that would put two
+// path-tracing pipelines on DIFFERENT streams of one device (they could then run concurrently: DESIGN.md 5.2) unless the caller takes
+// that over explicitly (RTGL_AMD_ALLOW_CONCURRENT_PIPELINES=1; RTGL_AMD_PRIVATE_STREAMS=1 implies it).
+static std::map<const rtgl_context *, std::pair<int, hipStream_t>> g_ctx_streams;
+static void register_ctx_stream(const rtgl_context *ctx, int device, hipStream_t st)
+{
+    std::lock_guard<std::mutex> lock(g_stream_mutex);
+    g_ctx_streams[ctx] = std::make_pair(device, st);
+}
+static void unregister_ctx_stream(const rtgl_context *ctx)
+{
+    std::lock_guard<std::mutex> lock(g_stream_mutex);
+    g_ctx_streams.erase(ctx);
+}
+static bool other_stream_in_use(const rtgl_context *ctx, int device, hipStream_t st)
+{
+    std::lock_guard<std::mutex> lock(g_stream_mutex);
+    for (const auto &kv : g_ctx_streams) if (kv.first != ctx && kv.second.first == device && kv.second.second != st) return true;
+    return false;
+}
+static bool concurrent_pipelines_allowed()
+{
+    const char *a = getenv("RTGL_AMD_ALLOW_CONCURRENT_PIPELINES"), *p = getenv("RTGL_AMD_PRIVATE_STREAMS");
+    return (a && atoi(a) != 0) || (p && atoi(p) != 0);
+}
+
 static void release_device_stream(int device, hipStream_t st, bool shared)
 {
     if (!shared) { (void)hipStreamDestroy(st); return; }
@@ -317,6 +344,7 @@ extern "C" int rtgl_create_tiled(rtgl_context **out, int width, int height, int 
     { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) ctx->n_cus = prop.multiProcessorCount; }
     CCHK(acquire_device_stream(device, &ctx->own_stream, &ctx->own_stream_shared));
     ctx->stream = ctx->own_stream;
+    register_ctx_stream(ctx, device, ctx->stream);
     CCHK(hipEventCreate(&ctx->ev0));
     CCHK(hipEventCreate(&ctx->ev1));
     size_t img_bytes = (size_t)std::max(ctx->local_rows, 1) * width * sizeof(float4);
@@ -336,6 +364,7 @@ extern "C" int rtgl_create_tiled(rtgl_context **out, int width, int height, int 
     return RTGL_OK;
 }
 
+static int flush_pending_noexcept(rtgl_context *ctx);
 extern "C" int rtgl_create(rtgl_context **out, int width, int height, int device)
 {
     return rtgl_create_tiled(out, width, height, device, 0, 1, 8);
@@ -344,6 +373,11 @@ extern "C" int rtgl_create(rtgl_context **out, int width, int height, int device
 extern "C" void rtgl_destroy(rtgl_context *ctx)
 {
     if (!ctx) return;
+    // frames a batching context still holds back are submitted, not dropped (a caller that only ever called rtgl_render_frame and then
+    // reads a bound device image after destroying the context would otherwise lose up to frame_batch - 1 frames)
+    if (!ctx->pending.empty() && hipSetDevice(ctx->device) == hipSuccess && flush_pending_noexcept(ctx) != RTGL_OK)
+        fprintf(stderr, "rtgl_destroy: %zu batched frame(s) could not be submitted: %s\n", ctx->pending.size(), ctx->error.c_str());
+    unregister_ctx_stream(ctx);
     for (auto &w : ctx->workers) {
         { std::lock_guard<std::mutex> lk(w->m); w->state = PartWorker::kQuit; }
         w->cv.notify_all();
@@ -354,6 +388,7 @@ extern "C" void rtgl_destroy(rtgl_context *ctx)
     ctx->parts.clear();
     (void)hipSetDevice(ctx->device);
     for (hipEvent_t e : ctx->part_done) (void)hipEventDestroy(e);
+    if (ctx->gather_done) (void)hipEventDestroy(ctx->gather_done);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
 #ifdef RT_SOLO_STAMPS
     if (ctx->d_dbg_log) {      // diagnostics build: where the waves of the solo scan spent their cycles, per bounce, summed over all frames
@@ -496,6 +531,18 @@ static int multi_gather(rtgl_context *ctx)
         }
     }
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (ctx->peer_copy) {
+        // the copies read every part's tile buffer on the ASSEMBLER's stream: the parts' next frames (their own streams) must not overwrite
+        // the tiles before the copies are through
+        if (!ctx->gather_done) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->gather_done, hipEventDisableTiming));
+        HIPCHK(ctx, hipEventRecord(ctx->gather_done, ctx->stream));
+        for (rtgl_context *part : ctx->parts)
+            if (part->stream != ctx->stream) {
+                HIPCHK(ctx, hipSetDevice(part->device));
+                HIPCHK(ctx, hipStreamWaitEvent(part->stream, ctx->gather_done, 0));
+            }
+        HIPCHK(ctx, hipSetDevice(ctx->device));
+    }
     ctx->gathered = true;
     return RTGL_OK;
 }
@@ -1102,6 +1149,7 @@ static bool batch_compatible(const FrameParams &a, const FrameParams &b)
     return a.samples == b.samples && a.max_bounce == b.max_bounce && a.use_envmap == b.use_envmap && memcmp(a.background, b.background, sizeof a.background) == 0;
 }
 
+static int flush_pending_noexcept(rtgl_context *ctx) { return flush_pending(ctx); }
 static int flush_pending(rtgl_context *ctx)
 {
     if (ctx->pending.empty()) return RTGL_OK;
@@ -1360,7 +1408,10 @@ extern "C" int rtgl_local_row_to_global(const rtgl_context *ctx, int lr)
 extern "C" void *rtgl_device_image(rtgl_context *ctx)
 {
     if (!ctx) return nullptr;
-    if (!ctx->pending.empty() && hipSetDevice(ctx->device) == hipSuccess) (void)flush_pending(ctx);     // frames a batching context still holds back
+    if (!ctx->pending.empty()) {                         // frames a batching context still holds back: a failed submission is an error, not a stale image
+        if (hipSetDevice(ctx->device) != hipSuccess) { ctx->error = "rtgl_device_image: hipSetDevice failed"; return nullptr; }
+        if (flush_pending(ctx) != RTGL_OK) return nullptr;      // (ctx->error holds the reason)
+    }
     return (void *)ctx->d_image;
 }
 
@@ -1376,8 +1427,14 @@ extern "C" int rtgl_set_stream(rtgl_context *ctx, void *hip_stream)
 {
     ENTER(ctx);
     if (!ctx->parts.empty()) return fail(ctx, RTGL_ERR_STATE, "a multi-device context owns one stream per device");
+    const hipStream_t want = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    if (want != ctx->own_stream && other_stream_in_use(ctx, ctx->device, want) && !concurrent_pipelines_allowed())
+        return fail(ctx, RTGL_ERR_STATE, "rtgl_set_stream: another context of this process renders on a different stream of this device; two path-tracing pipelines "
+                                         "running concurrently on one device have produced wrong frames (DESIGN.md 5.2).  Bind the SAME stream to all of them, or set "
+                                         "RTGL_AMD_ALLOW_CONCURRENT_PIPELINES=1 to take this over");
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    ctx->stream = want;
+    register_ctx_stream(ctx, ctx->device, ctx->stream);
     return RTGL_OK;
 }
 

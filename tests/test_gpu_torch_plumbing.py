@@ -111,3 +111,24 @@ def test_rccl_gather_path_on_a_one_rank_group(tmp_path, rt):
         ref.render(p)
     want = ref.read_image(); ref.close()
     assert (np.load(out).view(np.uint32) == want.view(np.uint32)).all()
+
+
+def test_set_stream_refuses_a_second_pipeline_stream_on_the_device(rt):
+    """All contexts of a process on one device share ONE stream; rtgl_set_stream must refuse a binding that would let two
+    path-tracing pipelines run concurrently, accept the same stream for all of them, and step aside when the caller
+    takes the ordering over (RTGL_AMD_ALLOW_CONCURRENT_PIPELINES=1)."""
+    import os
+    dev = torch.device("cuda", 0)
+    a = rt.host.Context(64, 64, device=0)
+    b = rt.host.Context(64, 64, device=0)
+    side = torch.cuda.Stream(device=dev)
+    with pytest.raises(rt.host.RtglError, match="different stream"):
+        a.set_stream(side.cuda_stream)                 # b still renders on the library's stream
+    os.environ["RTGL_AMD_ALLOW_CONCURRENT_PIPELINES"] = "1"
+    try:
+        a.set_stream(side.cuda_stream)                 # the caller has taken the ordering over
+    finally:
+        del os.environ["RTGL_AMD_ALLOW_CONCURRENT_PIPELINES"]
+    b.set_stream(side.cuda_stream)                     # the SAME stream for both: fine without the override
+    a.set_stream(0); b.set_stream(0)
+    a.close(); b.close()

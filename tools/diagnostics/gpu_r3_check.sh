@@ -2,7 +2,7 @@
 set -e
 mkdir -p gpurun_out
 make -s -C oracle liboracle.so
-timeout -k 10 1000 python -m pytest tests -m gpu -x -q > gpurun_out/r3_pytest.log 2>&1 || (tail -40 gpurun_out/r3_pytest.log; exit 1)
+timeout -k 10 1100 python -m pytest tests -m gpu -x -q > gpurun_out/r3_pytest.log 2>&1 || (tail -40 gpurun_out/r3_pytest.log; exit 1)
 tail -2 gpurun_out/r3_pytest.log
 timeout -k 10 300 python bench.py --steps 200 --warmup 10 --no-cpu-baseline > gpurun_out/r3_bench_C2.json 2> gpurun_out/r3_bench_C2.err || (tail -5 gpurun_out/r3_bench_C2.err; exit 1)
 for c in C4 C5; do
@@ -12,5 +12,5 @@ python - <<'PY'
 import json
 for n in ("C2","C4","C5"):
     d=json.load(open(f"gpurun_out/r3_bench_{n}.json")); r=d["roofline"]; cn=d["counters_per_frame"]
-    print(n, round(d["value"],2), "Mpaths/s", round(d["ms_per_step"],3), "ms", "scan launch ms", round(r["avg_launch_ms"],4), "culled", round(cn.get("culled_tests",0)/max(cn["triangle_tests"],1),4), "cand", cn["candidates"])
+    print(n, round(d["value"],2), "Mpaths/s", round(d["ms_per_step"],3), "ms", "scan launch ms", round(r["avg_launch_ms"],4), "frac (executed)", round(r["frac"],4), "culled", round(cn.get("culled_tests",0)/max(cn["triangle_tests"],1),4), "cand", cn["candidates"])
 PY
