@@ -292,7 +292,12 @@ struct SoloCfg {
 // diagnostics build (-DRT_SOLO_STAMPS): s_memtime stamps around the phases of a wave's life, summed into mf.dbg_log
 // (-DRT_SOLO_STAMPS=2: only the begin and the end of every wave, on the constant 100 MHz clock: mean and slowest wave per bounce in units
 // of 10 ns, to set against the launch durations of a profile -- what the distribution of work over the waves loses)
-#if defined(RT_SOLO_STAMPS) && RT_SOLO_STAMPS == 2
+#if defined(RT_SOLO_STAMPS) && RT_SOLO_STAMPS == 3
+// (-DRT_SOLO_STAMPS=3: begin and end of every wave on BOTH clocks: shader cycles / 100 MHz ticks = the clock the chip holds in this kernel)
+#define RT_STAMP(var) const unsigned long long var = 0
+#define RT_STAMP_ADD(acc, from, to)
+#define RT_STAMP_NOW() __builtin_amdgcn_s_memtime()
+#elif defined(RT_SOLO_STAMPS) && RT_SOLO_STAMPS == 2
 #define RT_STAMP(var) const unsigned long long var = 0
 #define RT_STAMP_ADD(acc, from, to)
 #define RT_STAMP_NOW() __builtin_amdgcn_s_memrealtime()
@@ -380,6 +385,66 @@ __global__ void __launch_bounds__(256) cull_items_kernel(WaveBuffers wb, uint32_
     if (kCount && culled) atomicAdd(&counters->culled_tests, culled);
 }
 
+// ---- culled bounces, planned work distribution: what every (granule, chunk) item will cost, as an inclusive prefix sum over the
+// granules of each chunk (plan_prefix[chunk * stride + granule]) and the chunks' totals.  Cost, in quarters of a tile: 4 x (tiles the
+// granule keeps in the chunk + ~6 tiles' worth for the item's set-up: ray fetch, four ray set-ups, pipeline fill and drain) when it keeps
+// any, 1 when it keeps none (reading its keep bits and stepping on is not free: with every empty item at cost 0 a wave of the
+// camera-ray bounce, 99.7 % culled, could be handed thousands of them in a row -- 5 ms for a launch that takes 0.07).  The scan
+// cuts the line of all items (chunk-major) into one equal-cost interval per block and each block's part of a chunk into one per wave:
+// with culling, items differ between nothing and 128 tiles, and a launch whose waves took their items in fixed turns lasted 1.5 x (bounce 1
+// of C2) to 2.4 x (bounce 4) its mean wave.  One block per chunk; also counts the culled tests (option "counters").
+constexpr uint32_t kPlanItemFixed = 6u;
+template <bool kCount>
+__global__ void __launch_bounds__(256) scan_plan_kernel(WaveBuffers wb, uint32_t bounce, uint32_t chunk_quads, uint32_t n_quads, Counters *__restrict__ counters)
+{
+    __shared__ uint32_t wsum[4];
+    __shared__ uint32_t carry;
+    const uint32_t n_rays = wb.counts[bounce], n_gran = (n_rays + 127u) >> 7;
+    const uint32_t c = blockIdx.x, q_begin = c * chunk_quads, q_end = min(q_begin + chunk_quads, n_quads);
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t n_tiles = q_begin < q_end ? (q_end - q_begin) * kMfQuadTiles : 0u;
+    uint32_t *const P = wb.plan_prefix + (size_t)c * wb.plan_stride;
+    unsigned long long culled = 0;
+    if (threadIdx.x == 0) carry = 0u;
+    __syncthreads();
+    for (uint32_t g0 = 0; g0 < n_gran; g0 += 256u) {
+        const uint32_t g = g0 + threadIdx.x;
+        uint32_t cost = 0u;
+        if (g < n_gran && n_tiles) {
+            const uint32_t kept = m128_popc(chunk_keep_bits(wb.keep + (size_t)g * wb.keep_words, q_begin * kMfQuadTiles, n_tiles));
+            cost = kept ? 4u * (kept + kPlanItemFixed) : 1u;
+            if (kCount) culled += (unsigned long long)(n_tiles - kept) * kMfTileTris * min(128u, n_rays - g * 128u);
+        }
+        uint32_t inc = cost;
+        for (int off = 1; off < 64; off <<= 1) { const uint32_t t = __shfl_up(inc, off); if (lane >= (uint32_t)off) inc += t; }
+        if (lane == 63u) wsum[wave] = inc;
+        __syncthreads();
+        uint32_t base = carry;
+        for (uint32_t w = 0; w < wave; ++w) base += wsum[w];
+        if (g < n_gran) store_through(P + g, base + inc);
+        __syncthreads();
+        if (threadIdx.x == 255u) carry = base + inc;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) store_through(wb.plan_total + c, carry);
+    if (kCount && culled) atomicAdd(&counters->culled_tests, culled);
+}
+// exclusive prefix of the chunks' totals (plan_base[0 .. n_chunks], 64 bits each): one wave
+__global__ void __launch_bounds__(64) scan_plan_base_kernel(WaveBuffers wb, uint32_t n_chunks)
+{
+    const uint32_t lane = threadIdx.x;
+    unsigned long long run = 0ull;
+    for (uint32_t c0 = 0; c0 < n_chunks; c0 += 64u) {
+        const uint32_t c = c0 + lane;
+        const unsigned long long t = c < n_chunks ? (unsigned long long)wb.plan_total[c] : 0ull;
+        unsigned long long inc = t;
+        for (int off = 1; off < 64; off <<= 1) { const unsigned long long u = __shfl_up(inc, off); if (lane >= (uint32_t)off) inc += u; }
+        if (c < n_chunks) store_through(wb.plan_base + c, run + inc - t);
+        run += __shfl(inc, 63);
+    }
+    if (lane == 0) store_through(wb.plan_base + n_chunks, run);
+}
+
 // W = waves per SIMD.  W = 1: the wave owns the register file (256 + AGPRs) and hides its own latencies (the rays of its next item
 // travel while it scans).  W = 2: two waves share a SIMD, 256 registers each; a wave alone can issue one vector instruction per 4 cycles
 // while the SIMD executes one per 2, so the second wave's VALU work runs beside the first one's and the stream becomes bound by
@@ -398,18 +463,21 @@ __global__ void __launch_bounds__(256) cull_items_kernel(WaveBuffers wb, uint32_
 //     a launch has few blocks per chunk and the chunks differ (C4: 79 chunks for 256 CUs, camera rays culled for some chunks and not
 //     for others: the static launch lasted 1.33x its mean wave; dynamic: 29.9 -> 33.9 Mpaths/s.  On C2 the static form is 14 %
 //     faster: 8 chunks, 32 blocks each).
-template <bool kCount, int W, bool kDyn>
+template <bool kCount, int W, int kDist>
 __global__ void __launch_bounds__(256 * W) __attribute__((amdgpu_waves_per_eu(W, W)))
 scan_solo_kernel(SceneView sc, WaveBuffers wb, MfView mf, uint32_t bounce, uint32_t chunk_quads, uint32_t n_chunks, Counters *__restrict__ counters, int debug_skip_exact, int cull)
 {
     using Cfg = SoloCfg;
-    constexpr bool dynamic = kDyn;                             // (a template parameter: the static form carries none of the claiming state)
+    constexpr bool dynamic = kDist == 1, planned = kDist == 2, hybrid = kDist == 3;  // (a template parameter: the static form carries none of the claiming state)
     constexpr int S = kSoloSets;
     constexpr uint32_t kWaves = 4u * (uint32_t)W, kThreads = 256u * (uint32_t)W;
     extern __shared__ uint4 lds_tiles[];                      // the chunk's A tiles, [quad][tile][panel][row]
     __shared__ uint2 lds_queue[kWaves * Cfg::kQueue];        // per-wave survivor queue, entry = (lane | tile in chunk << 8, 20-bit mask: bit 5 s + u = triangle u of the lane's half survived for ray set s)
     __shared__ uint32_t lds_pick;                             // the chunk the block scans next
 #ifdef RT_SOLO_STAMPS
+#if RT_SOLO_STAMPS == 3
+    const unsigned long long tr_wave_begin = __builtin_amdgcn_s_memrealtime();
+#endif
     const unsigned long long ts_wave_begin = RT_STAMP_NOW();
     unsigned long long tt_stage = 0, tt_rays = 0, tt_group = 0, tt_steady = 0, tt_park = 0, tt_flush = 0, tt_iters = 0, tt_culled = 0, tt_culled_n = 0, tt_tiles = 0;
 #endif
@@ -474,10 +542,35 @@ scan_solo_kernel(SceneView sc, WaveBuffers wb, MfView mf, uint32_t bounce, uint3
     constexpr uint32_t kXcds = 8;
     const bool by_xcd = gridDim.x >= kXcds * n_chunks;
     const uint32_t c_first = by_xcd ? (blockIdx.x / kXcds) % n_chunks : blockIdx.x % n_chunks;
+    // ---- planned: the block's interval (p_lo, p_hi] of the cost line of all items (chunk-major; plan_base = where each chunk starts).  An
+    // unculled launch needs no plan: every item costs the same, chunk c starts at c x granules.
+    typedef const unsigned long long __attribute__((address_space(4))) *ConstU64;
+    const ConstU64 pbase_k = (ConstU64)(uintptr_t)wb.plan_base;
+    auto chunk_base = [&](uint32_t cc) -> unsigned long long { return cull ? pbase_k[cc] : (unsigned long long)cc * n_gran; };
+    unsigned long long p_lo = 0ull, p_hi = 0ull;
+    uint32_t p_next = 0u;                                      // planned: the next chunk to look at
+    if constexpr (planned) {
+        const unsigned long long total = chunk_base(n_chunks);
+        // (128-bit product: the total can exceed 2^32 and there can be thousands of blocks)
+        p_lo = (unsigned long long)(((unsigned __int128)total * blockIdx.x) / gridDim.x);
+        p_hi = (unsigned long long)(((unsigned __int128)total * (blockIdx.x + 1u)) / gridDim.x);
+        uint32_t lo = 0u, hi = n_chunks;                       // last chunk that starts at or before p_lo
+        while (hi - lo > 1u) { const uint32_t mid = (lo + hi) >> 1; if (chunk_base(mid) <= p_lo) lo = mid; else hi = mid; }
+        p_next = lo;
+    }
+    bool first_chunk = true;
     for (uint32_t c_from = c_first;;) {
         // ---- dynamic: the block picks the next chunk (cyclically from c_from) that has unclaimed items; none: done
         RT_STAMP(ts_pick);
         uint32_t c = c_from;
+        if constexpr (planned) {
+            // the next chunk that has a part of the block's interval; none: done
+            while (p_next < n_chunks && chunk_base(p_next + 1u) <= p_lo) ++p_next;
+            if (p_lo == p_hi || p_next >= n_chunks || chunk_base(p_next) >= p_hi) break;
+            c = p_next++;
+            if (!first_chunk) __syncthreads();                 // every wave is done with the tiles of the previous chunk
+            first_chunk = false;
+        }
         if (dynamic) {
             __syncthreads();                                   // every wave is done with the tiles (and the pick) of the previous chunk
             if (wave == 0) {
@@ -531,20 +624,27 @@ scan_solo_kernel(SceneView sc, WaveBuffers wb, MfView mf, uint32_t bounce, uint3
         constexpr uint32_t kNone = 0xFFFFFFFFu;
         // (the address is made to look divergent: for a uniform one LLVM's atomic optimizer rewrites the operation into its wave-aggregated
         // form, which is no faster here and longer)
+        // hybrid: six of seven granules in fixed turns (nothing to wait for, every wave knows its next item), every seventh -- spread evenly
+        // over the queue, so that the tail looks like the rest -- claimed from the chunk's counter when the wave is through with its
+        // turns: with culling an item costs anything between nothing and 128 tiles, and fixed turns alone left the launch waiting for
+        // its unluckiest wave (1.5 x the mean wave on bounce 1 of C2, 2.4 x on bounce 4)
+        const uint32_t n_tail = hybrid ? n_gran / 7u : 0u, n_turns = n_gran - n_tail;
+        const uint32_t n_claimable = hybrid ? n_tail : n_items;
         auto claim = [&](uint32_t seen, uint32_t &lo, uint32_t &end) {
-            const uint32_t rem = n_items > seen ? n_items - seen : 0u;
-            const uint32_t n = min(max(rem / (4u * max(blocks_here, 1u) * kWaves), 1u), 16u);
+            const uint32_t rem = n_claimable > seen ? n_claimable - seen : 0u;
+            const uint32_t n = hybrid ? min(max(rem / (2u * max(blocks_here, 1u) * kWaves), 1u), 4u) : min(max(rem / (4u * max(blocks_here, 1u) * kWaves), 1u), 16u);
             uint32_t v = 0u;
             if (lane == 0) v = atomicAdd(counter + opaque_zero, n);
             const uint32_t at = __builtin_amdgcn_readfirstlane(v);
-            lo = min(at, n_items); end = min(at + n, n_items);
+            lo = min(at, n_claimable); end = min(at + n, n_claimable);
         };
+        bool tail = false;                                     // hybrid: the wave has finished its turns and claims
         // item k of the chunk: the granule and which of the chunk's tiles its rays cannot be rejected for (bit t: tile t must be
         // scanned).  Culled bounces: dynamic launches take the granule from the compacted list of cull_items_kernel; the keep bits come
         // from the granule's row (chunk_keep_bits), through the scalar cache.
         const ConstWords keep_k = (ConstWords)(uintptr_t)wb.keep;
         auto item_of = [&](uint32_t k, uint32_t &g, Mask128 &bits) {
-            g = k; bits = keep_all;
+            g = hybrid ? (tail ? 7u * k + 6u : (k / 6u) * 7u + k % 6u) : k; bits = keep_all;
             if (cull) {
                 if (dynamic) g = items_k[k];
                 bits = chunk_keep_bits(keep_k + (size_t)g * wb.keep_words, tile_begin, n_tiles);
@@ -552,11 +652,33 @@ scan_solo_kernel(SceneView sc, WaveBuffers wb, MfView mf, uint32_t bounce, uint3
         };
         uint32_t k, hi, step;
         if (dynamic) { step = 1u; claim(0u, k, hi); }
-        else { step = blocks_here * kWaves; k = rank_here * kWaves + (uint32_t)wave; hi = n_items; }
+        else if (planned) {
+            // the block's part (a, e] of this chunk's cost, an eighth (or a quarter) of it per wave, and the granules whose prefix
+            // sum falls into the wave's part: consecutive granules, no claim, no turn
+            const unsigned long long cb = chunk_base(c), ce = chunk_base(c + 1u);
+            const uint32_t a = (uint32_t)((p_lo > cb ? p_lo : cb) - cb), e = (uint32_t)((p_hi < ce ? p_hi : ce) - cb);
+            const uint32_t w_lo = a + (uint32_t)(((unsigned long long)(e - a) * (uint32_t)wave) / kWaves), w_hi = a + (uint32_t)(((unsigned long long)(e - a) * ((uint32_t)wave + 1u)) / kWaves);
+            const ConstWords P = (ConstWords)(uintptr_t)(wb.plan_prefix + (size_t)c * wb.plan_stride);
+            auto first_above = [&](uint32_t x) -> uint32_t {           // first granule whose inclusive prefix sum exceeds x
+                if (!cull) return min(x, n_gran);                        // (every item costs 1: the prefix of granule g is g + 1)
+                uint32_t lo = 0u, up = n_gran;
+                while (lo < up) { const uint32_t mid = (lo + up) >> 1; if (P[mid] > x) up = mid; else lo = mid + 1u; }
+                return lo;
+            };
+            step = 1u; k = first_above(w_lo); hi = first_above(w_hi);
+        }
+        else {
+            step = blocks_here * kWaves; k = rank_here * kWaves + (uint32_t)wave; hi = hybrid ? n_turns : n_items;
+            if (hybrid && k >= hi) { tail = true; step = 1u; claim(0u, k, hi); }
+        }
         uint32_t rec_k = kNone, rec_g = 0u;                    // the record of an item read ahead
         Mask128 rec_keep = {0ull, 0ull};
         uint32_t ray_k = kNone;                                // W = 1: the item whose rays are in (or on their way to) nxt_a / nxt_b
-        auto advance = [&]() { k += step; if (dynamic && k >= hi) claim(hi, k, hi); };      // (dynamic: the batch is used up)
+        auto advance = [&]() {
+            k += step;
+            if (dynamic && k >= hi) claim(hi, k, hi);          // (dynamic: the batch is used up)
+            if (hybrid && k >= hi) { if (tail) claim(hi, k, hi); else { tail = true; step = 1u; claim(0u, k, hi); } }
+        };
         while (k < hi) {
             RT_STAMP(ts_iter);
             uint32_t g; Mask128 keep;
@@ -565,7 +687,7 @@ scan_solo_kernel(SceneView sc, WaveBuffers wb, MfView mf, uint32_t bounce, uint3
             // the item after this one, if it is known already: its record (and with one wave per SIMD its rays) travel during the scan
             const uint32_t succ = k + step < hi ? k + step : kNone;
             if (succ != kNone) { item_of(succ, rec_g, rec_keep); rec_k = succ; }
-            if (kCount && cull && !dynamic && lane == 0)          // (dynamic launches count these in cull_items_kernel)
+            if (kCount && cull && !dynamic && !planned && lane == 0)          // (dynamic launches count these in cull_items_kernel, planned ones in scan_plan_kernel)
                 c_culled += (unsigned long long)(n_tiles - m128_popc(keep)) * kMfTileTris * min(128u, n_rays - wave_slot0);
             if (!m128_any(keep)) {                             // (static, culled bounce) nothing of this chunk can be hit by this granule's rays
                 if constexpr (W == 1) { if (succ != kNone && m128_any(rec_keep)) { fetch_rays(rec_g, nxt_a, nxt_b); ray_k = succ; } }
@@ -782,7 +904,7 @@ scan_solo_kernel(SceneView sc, WaveBuffers wb, MfView mf, uint32_t bounce, uint3
             tt_iters++; tt_tiles += n_tiles;
 #endif
         }
-        if (!dynamic) break;                                   // static: a block stays with the chunk it started on
+        if (!dynamic && !planned) break;                       // static: a block stays with the chunk it started on
     }
 #ifdef RT_SOLO_STAMPS
     if (lane == 0 && mf.dbg_log) {
@@ -793,11 +915,14 @@ scan_solo_kernel(SceneView sc, WaveBuffers wb, MfView mf, uint32_t bounce, uint3
         atomicAdd(d + 9, tt_tiles);
         if (blockIdx.x == 0 && wave == 0) d[15] = (unsigned long long)gridDim.x * kWaves;
         atomicMax(d + 10, ts_end - ts_wave_begin);                // slowest wave of this launch: summed per bounce by the narrow phase
-        if (!kDyn && bounce < 16u) {                              // static launches: wave time per chunk (the block's only one)
+        if (kDist == 0 && bounce < 16u) {                              // static launches: wave time per chunk (the block's only one)
             unsigned long long *pc = reinterpret_cast<unsigned long long *>(mf.dbg_log) + 2048ull + (16ull * bounce) * 64ull * 2ull + 2ull * (c_first % 512u);
             atomicAdd(pc, ts_end - ts_wave_begin); atomicAdd(pc + 1, 1ull);
         }
         atomicAdd(d + 11, tt_culled); atomicAdd(d + 12, tt_culled_n);
+#if RT_SOLO_STAMPS == 3
+        atomicAdd(d + 14, __builtin_amdgcn_s_memrealtime() - tr_wave_begin);
+#endif
     }
 #endif
     if (lane == 0) store_through(wb.cand_counts + region, (uint32_t)(appended < (unsigned long long)wb.cand_region ? appended : (unsigned long long)wb.cand_region));

@@ -210,6 +210,7 @@ struct rtgl_context {
     uint2 *d_items = nullptr; size_t items_capacity = 0;          // packet culling: per chunk of a culled scan launch its work items + one count per chunk
     uint32_t *d_sched = nullptr; size_t sched_capacity = 0;       // kernel 4: next unclaimed item per (bounce, chunk)
     uint32_t *d_keep = nullptr; size_t keep_capacity = 0;         // packet culling: (granules of 128 rays) x (quads / 32) words
+    void *d_plan = nullptr; size_t plan_capacity = 0;             // planned work distribution of culled scan launches: cost prefix sums per chunk
     void *d_stage = nullptr; size_t stage_capacity = 0;           // ray binning: the staging queue + (key, rank) per slot
     uint32_t *d_sort_hist = nullptr; uint32_t sort_bits_alloc = 0;
     float mesh_lo[3] = {0.0f, 0.0f, 0.0f}, mesh_ext = 0.0f;       // box of the triangles' finite vertices (origin cells of the bin key)
@@ -359,7 +360,7 @@ extern "C" int rtgl_create_tiled(rtgl_context **out, int width, int height, int 
     if (const char *k = getenv("RTGL_AMD_KERNEL")) { const int v = atoi(k); if (v >= RTGL_KERNEL_MEGA && v <= RTGL_KERNEL_WAVEFRONT_MFMA_SOLO && v != RTGL_KERNEL_REMOVED_3) { ctx->opt_kernel = v; ctx->kernel_explicit = true; } }
     if (const char *k = getenv("RTGL_AMD_SCAN_WAVES")) { const int v = atoi(k); if (v >= 0 && v <= 2) ctx->opt_scan_waves = v; }   // A/B of the scan's occupancy
     if (const char *k = getenv("RTGL_AMD_FRAME_BATCH")) { const int v = atoi(k); if (v >= 1 && v <= (int)kBatchMax) ctx->opt_frame_batch = v; }
-    if (const char *k = getenv("RTGL_AMD_SCAN_DYNAMIC")) { const int v = atoi(k); if (v >= 0 && v <= 2) ctx->opt_scan_dynamic = v; }   // ... and of its work distribution
+    if (const char *k = getenv("RTGL_AMD_SCAN_DYNAMIC")) { const int v = atoi(k); if (v >= 0 && v <= 4) ctx->opt_scan_dynamic = v; }   // ... and of its work distribution
     *out = ctx;
     return RTGL_OK;
 }
@@ -400,6 +401,17 @@ extern "C" void rtgl_destroy(rtgl_context *ctx)
                         b, d[8], d[7], tot / d[8], 100.0 * d[1] / tot, 100.0 * d[2] / tot, 100.0 * d[3] / tot, 100.0 * d[4] / tot, 100.0 * d[5] / tot, 100.0 * d[6] / tot,
                         d[9] ? (double)d[4] / (double)d[9] : 0.0, (double)d[13] * (double)d[15] / (double)d[8], d[12], d[12] ? (double)d[11] / (double)d[12] : 0.0);
             }
+#if RT_SOLO_STAMPS == 3
+        if (hipMemcpy(h, ctx->d_dbg_log, sizeof h, hipMemcpyDeviceToHost) == hipSuccess) {
+            double cyc = 0, ticks = 0;
+            for (int b = 0; b < 64 && h[16 * b + 8]; ++b) {
+                const unsigned long long *d = h + 16 * b;
+                fprintf(stderr, "rtgl clock bounce %2d: %llu waves, %.0f shader cycles per wave over %.0f ticks of 10 ns: %.3f GHz\n", b, d[8], (double)d[0] / d[8], (double)d[14] / d[8], d[14] ? (double)d[0] / (double)d[14] * 0.1 : 0.0);
+                cyc += (double)d[0]; ticks += (double)d[14];
+            }
+            if (ticks > 0) fprintf(stderr, "rtgl clock: in-kernel shader clock of scan_solo_kernel, wave-time weighted over all launches: %.3f GHz\n", cyc / ticks * 0.1);
+        }
+#endif
         // static launches: mean wave time per chunk, relative to the bounce's mean (what an uneven cost of the chunks loses)
         std::vector<unsigned long long> pc(16 * 64 * 2 * 16);
         if (hipMemcpy(pc.data(), reinterpret_cast<unsigned long long *>(ctx->d_dbg_log) + 2048, pc.size() * 8, hipMemcpyDeviceToHost) == hipSuccess)
@@ -415,7 +427,7 @@ extern "C" void rtgl_destroy(rtgl_context *ctx)
 #endif
     void *ptrs[] = { ctx->d_spheres, ctx->d_materials, ctx->d_vertices, ctx->d_sphere_visits, ctx->d_edges, ctx->d_planes,
                      ctx->d_env, ctx->d_image_own, ctx->d_rng, ctx->d_counters, ctx->d_u8, ctx->d_group_bounds, ctx->d_wave, ctx->d_counts, ctx->d_mf_groups, ctx->d_mf_A, ctx->d_mf_order,
-                     ctx->d_dbg_log, ctx->d_cand, ctx->d_stage, ctx->d_sort_hist, ctx->d_mf_cull, ctx->d_keep, ctx->d_items, ctx->d_sched, ctx->d_edges_s, ctx->d_planes_s, ctx->d_batch_rad };
+                     ctx->d_dbg_log, ctx->d_cand, ctx->d_plan, ctx->d_stage, ctx->d_sort_hist, ctx->d_mf_cull, ctx->d_keep, ctx->d_items, ctx->d_sched, ctx->d_edges_s, ctx->d_planes_s, ctx->d_batch_rad };
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (hipEvent_t e : ctx->kev) (void)hipEventDestroy(e);
     if (ctx->h_counts) (void)hipHostFree(ctx->h_counts);
@@ -940,12 +952,13 @@ static uint32_t solo_chunks(const rtgl_context *ctx)
     return (real_quads + chunk_quads - 1) / chunk_quads;
 }
 
-// work distribution of the scan (rt_scan.hpp): "scan_dynamic" 0 = by the mesh (dynamic from 1,024 quads = 41k triangles on: few blocks
-// per chunk), 1 = static, 2 = dynamic
+// work distribution of the scan (rt_scan.hpp): "scan_dynamic" 0 = by the mesh (hybrid; dynamic from 1,024 quads = 41k triangles on: few
+// blocks per chunk), 1 = static turns, 2 = dynamic claims, 3 = planned (equal-cost intervals of the item line, no atomics), 4 = hybrid
+// (turns + a claimed tail).  Returns the kernel's kDist: 0 static, 1 dynamic, 2 planned, 3 hybrid.
 static int solo_dynamic(const rtgl_context *ctx)
 {
     const uint32_t real_quads = std::min(ctx->n_mf_groups * ctx->mf_group_quads, (ctx->n_tri_visits + (uint32_t)kMfQuadTris - 1) / (uint32_t)kMfQuadTris);
-    return ctx->opt_scan_dynamic ? ctx->opt_scan_dynamic - 1 : (real_quads >= 1024u ? 1 : 0);
+    return ctx->opt_scan_dynamic ? ctx->opt_scan_dynamic - 1 : (real_quads >= 1024u ? 1 : 3);
 }
 
 static int launch_intersect_solo(rtgl_context *ctx, const SceneView &sc, uint32_t n0, uint32_t bounce, bool binned)
@@ -969,11 +982,13 @@ static int launch_intersect_solo(rtgl_context *ctx, const SceneView &sc, uint32_
            && (real_quads + chunk_quads / 2 - 1) / (chunk_quads / 2) <= (uint32_t)ctx->n_cus)
         chunk_quads /= 2u;
     const uint32_t chunks = (real_quads + chunk_quads - 1) / chunk_quads;
-    const int dynamic = solo_dynamic(ctx);
+    // (auto: the camera-ray bounce of a small mesh keeps its fixed turns -- almost every item is empty there and a claimed tail only adds
+    // round trips: 74 us against 168 on C2; the binned bounces take the hybrid form: 660 -> 589, 553 -> 499 us)
+    const int dist = (ctx->opt_scan_dynamic == 0 && bounce == 0 && solo_dynamic(ctx) == 3) ? 0 : solo_dynamic(ctx), dynamic = dist == 1;
     // one block per CU (forced by the LDS request); fewer when there is not an item per wave.  Static: the same number of blocks on
     // every chunk.
     uint32_t blocks = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(((uint64_t)est_gran * chunks + waves - 1) / waves, (uint64_t)ctx->n_cus));
-    if (!dynamic) blocks = std::max(1u, std::min((est_gran + waves - 1u) / waves, std::max(1u, (uint32_t)ctx->n_cus / chunks))) * chunks;
+    if (dist == 0 || dist == 3) blocks = std::max(1u, std::min((est_gran + waves - 1u) / waves, std::max(1u, (uint32_t)ctx->n_cus / chunks))) * chunks;
     const size_t lds = std::max<size_t>(((size_t)chunk_quads * kMfQuadTiles + 4) * 1024, 96 * 1024);   // + the four rows read two trips ahead behind the last tile; > half of the CU's LDS with the static queue: one block per CU
 #ifdef RT_SOLO_STAMPS
     if (!ctx->d_dbg_log) { HIPCHK(ctx, hipMalloc((void **)&ctx->d_dbg_log, (size_t)(2 + (2u << 22)) * 4)); HIPCHK(ctx, hipMemsetAsync(ctx->d_dbg_log, 0, 2048 * 8 + 16 * 64 * 2 * 16 * 8, ctx->stream)); }
@@ -982,10 +997,14 @@ static int launch_intersect_solo(rtgl_context *ctx, const SceneView &sc, uint32_
     if (!ctx->solo_attr_set) {
         // allow the whole LDS of a CU (160 KB) minus the kernel's static share as dynamic shared memory.  The attribute belongs to the
         // (function, device) pair, so it is raised once per context -- a context is bound to one device -- not once per process.
-        for (const void *fn : {reinterpret_cast<const void *>(&scan_solo_kernel<false, 1, false>), reinterpret_cast<const void *>(&scan_solo_kernel<true, 1, false>),
-                               reinterpret_cast<const void *>(&scan_solo_kernel<false, 2, false>), reinterpret_cast<const void *>(&scan_solo_kernel<true, 2, false>),
-                               reinterpret_cast<const void *>(&scan_solo_kernel<false, 1, true>), reinterpret_cast<const void *>(&scan_solo_kernel<true, 1, true>),
-                               reinterpret_cast<const void *>(&scan_solo_kernel<false, 2, true>), reinterpret_cast<const void *>(&scan_solo_kernel<true, 2, true>)}) {
+        for (const void *fn : {reinterpret_cast<const void *>(&scan_solo_kernel<false, 1, 0>), reinterpret_cast<const void *>(&scan_solo_kernel<true, 1, 0>),
+                               reinterpret_cast<const void *>(&scan_solo_kernel<false, 2, 0>), reinterpret_cast<const void *>(&scan_solo_kernel<true, 2, 0>),
+                               reinterpret_cast<const void *>(&scan_solo_kernel<false, 1, 1>), reinterpret_cast<const void *>(&scan_solo_kernel<true, 1, 1>),
+                               reinterpret_cast<const void *>(&scan_solo_kernel<false, 2, 1>), reinterpret_cast<const void *>(&scan_solo_kernel<true, 2, 1>),
+                               reinterpret_cast<const void *>(&scan_solo_kernel<false, 1, 2>), reinterpret_cast<const void *>(&scan_solo_kernel<true, 1, 2>),
+                               reinterpret_cast<const void *>(&scan_solo_kernel<false, 2, 2>), reinterpret_cast<const void *>(&scan_solo_kernel<true, 2, 2>),
+                               reinterpret_cast<const void *>(&scan_solo_kernel<false, 1, 3>), reinterpret_cast<const void *>(&scan_solo_kernel<true, 1, 3>),
+                               reinterpret_cast<const void *>(&scan_solo_kernel<false, 2, 3>), reinterpret_cast<const void *>(&scan_solo_kernel<true, 2, 3>)}) {
             hipFuncAttributes fattr;
             HIPCHK(ctx, hipFuncGetAttributes(&fattr, fn));
             HIPCHK(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024 - fattr.sharedSizeBytes)));
@@ -997,6 +1016,23 @@ static int launch_intersect_solo(rtgl_context *ctx, const SceneView &sc, uint32_
     const int cull = ctx->opt_cull == 2 || (ctx->opt_cull >= 1 && bounce == 0) || (ctx->opt_cull == 3 && binned);
     if (cull) {
         hipLaunchKernelGGL(packet_cull_kernel, dim3(std::max(1u, std::min((est_gran + 3u) / 4u, 8192u))), dim3(256), 0, ctx->stream, ctx->wb, ctx->d_mf_cull, real_quads * (uint32_t)kMfQuadTiles, bounce);
+        if (dist == 2) {
+            // planned: cost prefix sums per chunk [chunks x stride u32][chunks totals u32][chunks + 1 starts u64]
+            const uint32_t stride = n0 / Cfg::kRaysPerWave + 1u;
+            const size_t off_tot = (((size_t)chunks * stride * sizeof(uint32_t)) + 255) & ~(size_t)255, off_base = (off_tot + (size_t)chunks * sizeof(uint32_t) + 255) & ~(size_t)255;
+            const size_t need = off_base + ((size_t)chunks + 1) * sizeof(unsigned long long);
+            if (ctx->plan_capacity < need) {
+                if (ctx->d_plan) { HIPCHK(ctx, hipFree(ctx->d_plan)); ctx->d_plan = nullptr; }
+                HIPCHK(ctx, hipMalloc(&ctx->d_plan, need));
+                ctx->plan_capacity = need;
+            }
+            ctx->wb.plan_prefix = reinterpret_cast<uint32_t *>(ctx->d_plan); ctx->wb.plan_stride = stride;
+            ctx->wb.plan_total = reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(ctx->d_plan) + off_tot);
+            ctx->wb.plan_base = reinterpret_cast<unsigned long long *>(reinterpret_cast<uint8_t *>(ctx->d_plan) + off_base);
+            if (ctx->opt_counters) hipLaunchKernelGGL(scan_plan_kernel<true>, dim3(chunks), dim3(256), 0, ctx->stream, ctx->wb, bounce, chunk_quads, real_quads, ctx->d_counters);
+            else hipLaunchKernelGGL(scan_plan_kernel<false>, dim3(chunks), dim3(256), 0, ctx->stream, ctx->wb, bounce, chunk_quads, real_quads, ctx->d_counters);
+            hipLaunchKernelGGL(scan_plan_base_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->wb, chunks);
+        }
         if (dynamic) {
         // work items of the culled launch: [one count per chunk][chunks x (granules of the whole image) entries]
         const uint32_t stride = n0 / Cfg::kRaysPerWave + 1u;
@@ -1019,8 +1055,10 @@ static int launch_intersect_solo(rtgl_context *ctx, const SceneView &sc, uint32_
     // rank of eight 0.73 -> 0.76-0.85 ms)
 #define RTGL_LAUNCH_SCAN(C, WW, D) hipLaunchKernelGGL((scan_solo_kernel<C, WW, D>), dim3(blocks), dim3(256 * WW), lds, ctx->stream, sc, ctx->wb, mf, bounce, chunk_quads, chunks, ctx->d_counters, ctx->opt_debug_skip_exact, cull)
 #define RTGL_LAUNCH_SCAN_W(C, D) do { if (W == 2) RTGL_LAUNCH_SCAN(C, 2, D); else RTGL_LAUNCH_SCAN(C, 1, D); } while (0)
-    if (dynamic) { if (ctx->opt_counters) RTGL_LAUNCH_SCAN_W(true, true); else RTGL_LAUNCH_SCAN_W(false, true); }
-    else { if (ctx->opt_counters) RTGL_LAUNCH_SCAN_W(true, false); else RTGL_LAUNCH_SCAN_W(false, false); }
+    if (dist == 1) { if (ctx->opt_counters) RTGL_LAUNCH_SCAN_W(true, 1); else RTGL_LAUNCH_SCAN_W(false, 1); }
+    else if (dist == 2) { if (ctx->opt_counters) RTGL_LAUNCH_SCAN_W(true, 2); else RTGL_LAUNCH_SCAN_W(false, 2); }
+    else if (dist == 3) { if (ctx->opt_counters) RTGL_LAUNCH_SCAN_W(true, 3); else RTGL_LAUNCH_SCAN_W(false, 3); }
+    else { if (ctx->opt_counters) RTGL_LAUNCH_SCAN_W(true, 0); else RTGL_LAUNCH_SCAN_W(false, 0); }
 #undef RTGL_LAUNCH_SCAN_W
 #undef RTGL_LAUNCH_SCAN
     HIPCHK(ctx, hipGetLastError());
@@ -1047,7 +1085,7 @@ static int launch_wavefront(rtgl_context *ctx, const SceneView &sc, const std::v
     for (uint32_t s = 0; s < P.samples; ++s) {
         const uint32_t n_counts = ctx->counts_capacity + 1u <= 256u ? ctx->counts_capacity + 1u : 0u;      // cleared by generate_rays_kernel's first block
         if (!n_counts) HIPCHK(ctx, hipMemsetAsync(ctx->d_counts, 0, counts_bytes(ctx->counts_capacity), ctx->stream));
-        if (ctx->opt_kernel == RTGL_KERNEL_WAVEFRONT_MFMA_SOLO && ctx->d_sched && solo_dynamic(ctx))       // the scan launches' work counters (rt_scan.hpp)
+        if (ctx->opt_kernel == RTGL_KERNEL_WAVEFRONT_MFMA_SOLO && ctx->d_sched && (solo_dynamic(ctx) == 1 || solo_dynamic(ctx) == 3))  // the scan launches' work counters (rt_scan.hpp)
             HIPCHK(ctx, hipMemsetAsync(ctx->d_sched, 0, (size_t)(P.max_bounce + 2) * ctx->wb.sched_stride * sizeof(uint32_t), ctx->stream));
         for (uint32_t f = 0; f < B; ++f)
             hipLaunchKernelGGL(generate_rays_kernel, gen_grid, dim3(256), 0, ctx->stream, frames[f], im, ctx->wb, s, n0_frame,
@@ -1508,7 +1546,7 @@ extern "C" int rtgl_set_option(rtgl_context *ctx, const char *key, int value)
         if (value < 0 || value > 2) return fail(ctx, RTGL_ERR_INVALID, "scan_waves (waves per SIMD of the kernel-4 scan) must be 0 (default: two), 1 or 2");
         ctx->opt_scan_waves = value;
     } else if (!strcmp(key, "scan_dynamic")) {
-        if (value < 0 || value > 2) return fail(ctx, RTGL_ERR_INVALID, "scan_dynamic must be 0 (chosen by the mesh), 1 (static) or 2 (dynamic)");
+        if (value < 0 || value > 4) return fail(ctx, RTGL_ERR_INVALID, "scan_dynamic must be 0 (chosen by the mesh), 1 (static turns), 2 (dynamic claims), 3 (planned: equal-cost intervals) or 4 (hybrid: turns + a claimed tail)");
         ctx->opt_scan_dynamic = value;
     } else if (!strcmp(key, "frame_batch")) {
         if (value < 1 || value > (int)kBatchMax) return fail(ctx, RTGL_ERR_INVALID, "frame_batch (consecutive frames traced in one set of launches) must be 1..16");

@@ -42,7 +42,7 @@ def run_cases(rt, oracle, N, seed):
         p0 = sc.FrameParams(max_bounce=int(rng.integers(1, 9)), use_envmap=int(scene.env is not None), use_dof=int(rng.integers(2)),
                             camera_position=(float(rng.uniform(-5, 5)), float(rng.uniform(-4, 2)), float(rng.uniform(-40, -20))), camera_forward=fwd, camera_right=right,
                             camera_aperture=float(rng.choice([0.001, 0.05, 0.5])), camera_focal_length=float(rng.uniform(8, 45)))
-        opts = dict(kernel=4, scan_waves=int(rng.integers(0, 3)), scan_dynamic=int(rng.integers(0, 3)), cull=int(rng.integers(0, 4)), sort_min_rays=int(rng.choice([0, 0, 3000, 65536])),
+        opts = dict(kernel=4, scan_waves=int(rng.integers(0, 3)), scan_dynamic=int(rng.integers(0, 5)), cull=int(rng.integers(0, 4)), sort_min_rays=int(rng.choice([0, 0, 3000, 65536])),
                     mf_chunk_quads=int(rng.choice([1, 2, 3, 5, 8, 16, 32])), mf_group_quads=int(rng.choice([1, 2, 4, 8, 32, 64])))
         frames = int(rng.integers(1, 4))
         ctx = rt.host.Context(W, H)
