@@ -729,12 +729,13 @@ __global__ void __launch_bounds__(256) shade_kernel(SceneView sc, FrameParams P,
         uint32_t wave_base = s_cnt[4];
         for (int w = 0; w < wave; ++w) wave_base += s_cnt[w];
         const uint32_t out_slot = wave_base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-        store_ray(qout, out_slot, s);
         if (kSort) {
+            // (the bin's counter first: its round trip -- a device-scope atomic is performed at the memory side -- runs beside the ray's stores)
             const uint32_t key = ray_bin_key(wb, s.o, s.d);
             const uint32_t rank = atomicAdd(wb.sort_hist + key, 1u);
+            store_ray(qout, out_slot, s);
             store_through(reinterpret_cast<unsigned long long *>(wb.sort_kr + out_slot), (unsigned long long)key | ((unsigned long long)rank << 32));
-        } else store_through(best_out + out_slot, kNoHitKey);
+        } else { store_ray(qout, out_slot, s); store_through(best_out + out_slot, kNoHitKey); }
     }
     __syncthreads();                                                              // s_cnt is rewritten by the next batch
     }
