@@ -69,7 +69,7 @@ template <bool kMax> __device__ __forceinline__ float full_reduce(float x)
 // non-finite origin, a direction that cannot be normalised, or directions spread too widely to have an axis keeps every tile.
 // (Round 2 first evaluated the certificate inside the scan, per (wave, chunk) item: ~5,000 cycles per item for a scalar load of the
 // bounds, a conflict-ridden LDS read of the chunk's records and the test itself, 40 % of the camera-ray bounce.)
-__global__ void __launch_bounds__(256) packet_cull_kernel(WaveBuffers wb, const MfCull *__restrict__ cull, uint32_t n_tiles, uint32_t bounce)
+__global__ void __launch_bounds__(256) packet_cull_kernel(WaveBuffers wb, const MfCull *__restrict__ cull, uint32_t n_tiles, uint32_t bounce, float ro_add, float sigma_add)
 {
     const uint32_t n_rays = wb.counts[bounce];
     const RayQueue qin = (bounce & 1u) ? wb.q[1] : wb.q[0];
@@ -109,7 +109,9 @@ __global__ void __launch_bounds__(256) packet_cull_kernel(WaveBuffers wb, const 
                 const f3 eo = o[k] - pk.O, ed = dh[k] - pk.D;
                 ro = fmaxf(ro, __builtin_amdgcn_sqrtf(dot3(eo, eo))); sigma = fmaxf(sigma, __builtin_amdgcn_sqrtf(dot3(ed, ed)));
             }
-        pk.ro = full_reduce<true>(ro) * 1.0001f + 1e-30f; pk.sigma = full_reduce<true>(sigma) * 1.0001f + 2e-6f;
+        // (ro_add, sigma_add: the camera-ray bits are kept for the frames that follow while the camera stands still; their rays differ from
+        // this frame's by the depth-of-field jitter only, which the host bounds -- rtgl_amd.hip, camera_keep_valid)
+        pk.ro = full_reduce<true>(ro) * 1.0001f + 1e-30f + ro_add; pk.sigma = full_reduce<true>(sigma) * 1.0001f + 2e-6f + sigma_add;
         usable = !__any(!usable) && (Dl > 0.25f);
         pk.On = __builtin_amdgcn_sqrtf(dot3(pk.O, pk.O)) * 1.0001f + pk.ro;
         uint32_t *const row = wb.keep + (size_t)g * wb.keep_words;
@@ -799,7 +801,7 @@ scan_solo_kernel(SceneView sc, WaveBuffers wb, MfView mf, uint32_t bounce, uint3
                 th0 = ths[0]; th1 = ths[1]; th2 = ths[2]; th3 = ths[3];
                 typedef const uint4 __attribute__((address_space(3))) *LdsRow;
                 const uint32_t n_kept = m128_popc(seg);
-                if (n_kept == ts1 - ts0) {
+                if (n_kept == ts1 - ts0 && debug_skip_exact != 3) {     // (debug_skip_exact = 3: timing diagnostics, every segment through the list loop)
                     // ---- the whole segment: consecutive tiles [t0, t1), rows read two trips ahead by address increment
                     const uint32_t t0 = ts0, t1 = ts1;
                     // prologue: the products of the first tile.  The four rows behind the chunk's last tile are allocated (and never used).

@@ -209,7 +209,12 @@ struct rtgl_context {
     // in place by the scan, so every size is correct; a too small one is only slower)
     uint2 *d_items = nullptr; size_t items_capacity = 0;          // packet culling: per chunk of a culled scan launch its work items + one count per chunk
     uint32_t *d_sched = nullptr; size_t sched_capacity = 0;       // kernel 4: next unclaimed item per (bounce, chunk)
-    uint32_t *d_keep = nullptr; size_t keep_capacity = 0;         // packet culling: (granules of 128 rays) x (quads / 32) words
+    uint32_t *d_keep = nullptr; size_t keep_capacity = 0;         // packet culling: (granules of 128 rays) x (tiles / 32) words
+    // the camera-ray bounce's keep bits, kept across frames while camera, image and scene stand still (a progressive render's normal state):
+    // the camera rays of two frames differ by the depth-of-field jitter only, so bits certified for one frame's rays with the packet bounds
+    // widened by that jitter hold for all of them and packet_cull_kernel is skipped on bounce 0 (a third of its work)
+    uint32_t *d_keep0 = nullptr; size_t keep0_capacity = 0; bool keep0_valid = false; FrameParams keep0_params{}; uint32_t keep0_n0 = 0, keep0_words = 0; uint64_t keep0_scene = 0;
+    uint64_t scene_version = 0;
     void *d_plan = nullptr; size_t plan_capacity = 0;             // planned work distribution of culled scan launches: cost prefix sums per chunk
     void *d_stage = nullptr; size_t stage_capacity = 0;           // ray binning: the staging queue + (key, rank) per slot
     uint32_t *d_sort_hist = nullptr; uint32_t sort_bits_alloc = 0;
@@ -427,7 +432,7 @@ extern "C" void rtgl_destroy(rtgl_context *ctx)
 #endif
     void *ptrs[] = { ctx->d_spheres, ctx->d_materials, ctx->d_vertices, ctx->d_sphere_visits, ctx->d_edges, ctx->d_planes,
                      ctx->d_env, ctx->d_image_own, ctx->d_rng, ctx->d_counters, ctx->d_u8, ctx->d_group_bounds, ctx->d_wave, ctx->d_counts, ctx->d_mf_groups, ctx->d_mf_A, ctx->d_mf_order,
-                     ctx->d_dbg_log, ctx->d_cand, ctx->d_plan, ctx->d_stage, ctx->d_sort_hist, ctx->d_mf_cull, ctx->d_keep, ctx->d_items, ctx->d_sched, ctx->d_edges_s, ctx->d_planes_s, ctx->d_batch_rad };
+                     ctx->d_dbg_log, ctx->d_cand, ctx->d_keep0, ctx->d_plan, ctx->d_stage, ctx->d_sort_hist, ctx->d_mf_cull, ctx->d_keep, ctx->d_items, ctx->d_sched, ctx->d_edges_s, ctx->d_planes_s, ctx->d_batch_rad };
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (hipEvent_t e : ctx->kev) (void)hipEventDestroy(e);
     if (ctx->h_counts) (void)hipHostFree(ctx->h_counts);
@@ -729,6 +734,7 @@ static int rebuild_triangles(rtgl_context *ctx)
     if (ctx->d_edges) { HIPCHK(ctx, hipFree(ctx->d_edges)); ctx->d_edges = nullptr; }
     if (ctx->d_planes) { HIPCHK(ctx, hipFree(ctx->d_planes)); ctx->d_planes = nullptr; }
     ctx->n_tri_visits = (uint32_t)visit_tri.size();
+    ctx->scene_version++;
     {
         float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
         const float *vx = reinterpret_cast<const float *>(ctx->h_vertices.data());
@@ -961,7 +967,27 @@ static int solo_dynamic(const rtgl_context *ctx)
     return ctx->opt_scan_dynamic ? ctx->opt_scan_dynamic - 1 : (real_quads >= 1024u ? 1 : 3);
 }
 
-static int launch_intersect_solo(rtgl_context *ctx, const SceneView &sc, uint32_t n0, uint32_t bounce, bool binned)
+// may the camera-ray keep bits computed for frame `a` serve frame `b`?  Same camera; then the rays differ by the jitter of camera_ray (:187-195)
+// only: origins by at most 2 |aperture|, unit directions by at most 2 |aperture| / (|focal| - |aperture|)
+static bool same_camera(const FrameParams &a, const FrameParams &b)
+{
+    return a.use_dof == b.use_dof && a.cam_fov == b.cam_fov && a.cam_aperture == b.cam_aperture && a.cam_focal == b.cam_focal
+           && memcmp(a.cam_pos, b.cam_pos, sizeof a.cam_pos) == 0 && memcmp(a.cam_forward, b.cam_forward, sizeof a.cam_forward) == 0
+           && memcmp(a.cam_up, b.cam_up, sizeof a.cam_up) == 0 && memcmp(a.cam_right, b.cam_right, sizeof a.cam_right) == 0;
+}
+static bool camera_keep_widening(const FrameParams &P, float *ro_add, float *sigma_add)
+{
+    *ro_add = *sigma_add = 0.0f;
+    if (!P.use_dof) return true;                         // the same ray every frame, bit for bit
+    const float a = fabsf(P.cam_aperture), f = fabsf(P.cam_focal);
+    const float pn = sqrtf(P.cam_pos[0] * P.cam_pos[0] + P.cam_pos[1] * P.cam_pos[1] + P.cam_pos[2] * P.cam_pos[2]);
+    if (!(a < 0.25f * f) || !(f < 1.0e18f) || !(pn < 1.0e18f)) return false;     // (NaN included) no bound worth having: certify every frame's rays
+    *ro_add = 2.0f * a * 1.001f + 1.0e-5f * (1.0f + pn);
+    *sigma_add = 2.0f * a / (f - a) * 1.001f + 4.0e-6f;
+    return true;
+}
+
+static int launch_intersect_solo(rtgl_context *ctx, const SceneView &sc, uint32_t n0, uint32_t bounce, bool binned, const FrameParams *cam)
 {
     const uint32_t gq = ctx->mf_group_quads, n_quads = ctx->n_mf_groups * gq;
     const uint32_t real_quads = std::min(n_quads, (ctx->n_tri_visits + (uint32_t)kMfQuadTris - 1) / (uint32_t)kMfQuadTris);
@@ -1015,7 +1041,22 @@ static int launch_intersect_solo(rtgl_context *ctx, const SceneView &sc, uint32_
     // 0 never, 1 bounce 0, 2 every bounce as the queues come, 3 (default) bounce 0 and the binned bounces)
     const int cull = ctx->opt_cull == 2 || (ctx->opt_cull >= 1 && bounce == 0) || (ctx->opt_cull == 3 && binned);
     if (cull) {
-        hipLaunchKernelGGL(packet_cull_kernel, dim3(std::max(1u, std::min((est_gran + 3u) / 4u, 8192u))), dim3(256), 0, ctx->stream, ctx->wb, ctx->d_mf_cull, real_quads * (uint32_t)kMfQuadTiles, bounce);
+        // camera-ray bounce of a single frame: the bits of an earlier frame of the same camera, image and scene, if there are any
+        float ro_add = 0.0f, sigma_add = 0.0f;
+        bool have_bits = false;
+        if (bounce == 0 && cam && camera_keep_widening(*cam, &ro_add, &sigma_add) && !getenv("RTGL_AMD_NO_CAMERA_KEEP")) {
+            const size_t need = ((size_t)n0 / 128 + 16) * ctx->wb.keep_words;
+            if (ctx->keep0_capacity < need) {
+                if (ctx->d_keep0) { HIPCHK(ctx, hipFree(ctx->d_keep0)); ctx->d_keep0 = nullptr; }
+                HIPCHK(ctx, hipMalloc((void **)&ctx->d_keep0, need * sizeof(uint32_t)));
+                ctx->keep0_capacity = need; ctx->keep0_valid = false;
+            }
+            have_bits = ctx->keep0_valid && ctx->keep0_n0 == n0 && ctx->keep0_words == ctx->wb.keep_words && ctx->keep0_scene == ctx->scene_version && same_camera(ctx->keep0_params, *cam);
+            ctx->wb.keep = ctx->d_keep0;
+            if (!have_bits) { ctx->keep0_valid = true; ctx->keep0_n0 = n0; ctx->keep0_words = ctx->wb.keep_words; ctx->keep0_scene = ctx->scene_version; ctx->keep0_params = *cam; }
+        } else { ctx->wb.keep = ctx->d_keep; ro_add = sigma_add = 0.0f; }
+        if (!have_bits)
+        hipLaunchKernelGGL(packet_cull_kernel, dim3(std::max(1u, std::min((est_gran + 3u) / 4u, 8192u))), dim3(256), 0, ctx->stream, ctx->wb, ctx->d_mf_cull, real_quads * (uint32_t)kMfQuadTiles, bounce, ro_add, sigma_add);
         if (dist == 2) {
             // planned: cost prefix sums per chunk [chunks x stride u32][chunks totals u32][chunks + 1 starts u64]
             const uint32_t stride = n0 / Cfg::kRaysPerWave + 1u;
@@ -1096,7 +1137,7 @@ static int launch_wavefront(rtgl_context *ctx, const SceneView &sc, const std::v
             if (ctx->opt_kernel == RTGL_KERNEL_WAVEFRONT_SPLIT || ctx->opt_kernel == RTGL_KERNEL_WAVEFRONT_MFMA_SOLO) {
                 if (sc.n_tri_visits > 0 && ctx->opt_kernel == RTGL_KERNEL_WAVEFRONT_MFMA_SOLO) {
                     kev_mark(ctx);
-                    { const int rc = launch_intersect_solo(ctx, sc, n0, b, binned); if (rc) return rc; }
+                    { const int rc = launch_intersect_solo(ctx, sc, n0, b, binned, (B == 1 && P.samples == 1u) ? &P : nullptr); if (rc) return rc; }
                     kev_mark(ctx);
                 } else if (sc.n_tri_visits > 0) {
                     kev_mark(ctx);
@@ -1537,8 +1578,8 @@ extern "C" int rtgl_set_option(rtgl_context *ctx, const char *key, int value)
         if (value < kBoundGroup || value % kBoundGroup || (uint32_t)value > kMaxChunk) return fail(ctx, RTGL_ERR_INVALID, "wf_chunk must be a multiple of 64 in [64, 4096]");
         ctx->opt_wf_chunk = value;
     } else if (!strcmp(key, "debug_skip_exact")) {      // timing diagnostics only: the image is wrong
-        if (value < 0 || value > 2) return fail(ctx, RTGL_ERR_INVALID, "debug_skip_exact must be 0, 1 or 2");
-        ctx->opt_debug_skip_exact = value;               // 1: survivors are dropped instead of tested; 2: broad phase rejects everything
+        if (value < 0 || value > 3) return fail(ctx, RTGL_ERR_INVALID, "debug_skip_exact must be 0, 1, 2 or 3");
+        ctx->opt_debug_skip_exact = value;               // 1: survivors are dropped instead of tested; 2: broad phase rejects everything; 3: every segment through the list loop (image right)
     } else if (!strcmp(key, "mf_chunk_quads")) {
         if (value < 1 || (uint32_t)value > kMfMaxChunkQuads) return fail(ctx, RTGL_ERR_INVALID, "mf_chunk_quads must be in [1, 32]");
         ctx->opt_mf_chunk_quads = value;

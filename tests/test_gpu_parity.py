@@ -126,3 +126,49 @@ def test_triangle_free_scene_defaults_to_the_megakernel_and_explicit_choice_wins
     ctx.render(sc.params_c2().replace(frames=1, random=1))
     assert ctx.get_option("kernel_in_use") == 4
     ctx.close()
+
+
+def test_camera_ray_keep_bits_are_reused_only_while_they_are_valid(rt, oracle):
+    """The camera-ray bounce's keep bits are kept across frames while camera, image and scene stand still (rtgl_amd.hip, `d_keep0`; the
+    packet bounds are widened by the depth-of-field jitter).  One context through a sequence that keeps, invalidates and rebuilds them --
+    wide aperture, moved camera, depth of field off, a new mesh, an aperture too wide for any bound -- against the oracle after every
+    frame, and once more with the reuse switched off (RTGL_AMD_NO_CAMERA_KEEP): the same images."""
+    import os
+    sc = rt.scenes
+    W, H = 296, 184
+    scene_a, scene_b = sc.scene_mesh(36, 18, env_size=16), sc.scene_mesh(20, 28, env_size=16)
+    base = sc.params_c2().replace(max_bounce=4)
+    cams = [dict(camera_aperture=0.5, camera_focal_length=38.0), dict(camera_aperture=0.5, camera_focal_length=38.0), dict(camera_aperture=0.5, camera_focal_length=38.0),
+            dict(camera_aperture=0.5, camera_focal_length=38.0, camera_position=(2.0, 1.0, -33.0)), dict(camera_aperture=0.5, camera_focal_length=38.0, camera_position=(2.0, 1.0, -33.0)),
+            dict(use_dof=0), dict(use_dof=0), dict(camera_aperture=0.001), "scene_b", dict(camera_aperture=0.001), dict(camera_aperture=0.001),
+            dict(camera_aperture=12.0, camera_focal_length=10.0), dict(camera_aperture=12.0, camera_focal_length=10.0)]
+
+    def run(check):
+        ctx = rt.host.Context(W, H)
+        ctx.upload_scene(scene_a)
+        scene = scene_a
+        img_o = np.zeros((H, W, 4), np.float32)
+        g = sc.GlibcRand(3)
+        f = 0
+        for step in cams:
+            if step == "scene_b":
+                ctx.upload_scene(scene_b); scene = scene_b
+                continue
+            f += 1
+            p = base.replace(frames=f, random=g.rand(), **step)
+            ctx.render(p)
+            if check:
+                oracle.render(scene, p, img_o, threads=8)
+                got = ctx.read_image()
+                assert (got.view(np.uint32) == img_o.view(np.uint32)).all(), f"frame {f} ({step}) differs from the oracle"
+        img = ctx.read_image()
+        ctx.close()
+        return img
+
+    a = run(True)
+    os.environ["RTGL_AMD_NO_CAMERA_KEEP"] = "1"
+    try:
+        b = run(False)
+    finally:
+        del os.environ["RTGL_AMD_NO_CAMERA_KEEP"]
+    assert (a.view(np.uint32) == b.view(np.uint32)).all()
