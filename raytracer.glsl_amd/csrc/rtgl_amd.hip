@@ -3,6 +3,7 @@
 // -ffp-contract=off).  There is no CPU fallback: without a HIP device every entry point fails.
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -677,24 +678,44 @@ static int rebuild_sphere_visits(rtgl_context *ctx)
     return RTGL_OK;
 }
 
-// Storage order of the triangle visits for the matrix-core broad phase: the leaves of a k-d tree over the triangle centroids (median
-// split along the longest axis of the centroid box), written out left to right.  A leaf is one MFMA tile (10 triangles); the split
-// positions are multiples of the unit above them (tile -> quad of 4 tiles -> group of `group_tris` triangles), so every tile, quad and
-// group of the storage order is one subtree: spatially compact at every level (a bumpy height field sorted by Morton code put 40
-// consecutive triangles into cells 4.5 units across where 2.6 are possible -- and wide cells are what defeats the culling
-// certificates of rt_mfma.hpp: their bounds are per tile).  Only tightness depends on the order: hits merge by VISIT index.
-// Non-finite centroids sort as 0.  Deterministic: ties break by visit index.
+// Storage order of the triangle visits for the matrix-core broad phase: the leaves of a k-d tree (median split along the longest axis),
+// written out left to right.  A leaf is one MFMA tile (10 triangles); the split positions are multiples of the unit above them (tile ->
+// quad of 4 tiles -> group of `group_tris` triangles), so every tile, quad and group of the storage order is one subtree.
+//   * down to the groups the tree splits the triangle CENTROIDS: a group shares one local origin and one set of bounds in the bf16
+//     broad phase (rt_mfma.hpp), whose margin grows with the group's extent;
+//   * inside a group it splits the six-dimensional points (centroid, lambda x unit normal), lambda = a fifth of the mesh's extent: a
+//     tile's culling record (rt_mfma.hpp, MfCull) bounds its ten normals by a rectangle, and on a mesh that is coarse against its own
+//     curvature (the 100,000-triangle benchmark field turns by 15 degrees from one cell to the next) ten NEIGHBOURS spread +-33 degrees --
+//     a quarter of all far tiles then fail the certificates on their normals alone.  Ten triangles of similar slope from anywhere in
+//     the group (3 units across there) spread +-9 degrees; that the tile's sphere grows from 0.5 to 1.5 units costs far less
+//     (emulated on real bounce-1 rays, tools/diagnostics/cull_emulation.py: 49 -> 64 % of the tile tests certified at 100k triangles,
+//     88 -> 97 % on its camera bounce; 67 -> 70 % and 99.6 -> 98.9 % at 10k).
+// Only tightness depends on the order: hits merge by VISIT index.  Non-finite centroids and degenerate normals sort as 0.
+// Deterministic: ties break by visit index.
 static std::vector<uint32_t> kd_order(const rtgl_context *ctx, const std::vector<uint32_t> &visit_tri, uint32_t group_tris)
 {
     const size_t n = visit_tri.size();
     const float *vx = reinterpret_cast<const float *>(ctx->h_vertices.data());
-    std::vector<float> cen(3 * n);
-    for (size_t v = 0; v < n; ++v)
+    std::vector<float> pts(6 * n);
+    float blo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, bhi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+    auto finite = [](float c) { return c == c && c > -1.0e30f && c < 1.0e30f; };
+    for (size_t v = 0; v < n; ++v) {
+        const float *t = vx + (size_t)visit_tri[v] * 12;
         for (int a = 0; a < 3; ++a) {
-            const float *t = vx + (size_t)visit_tri[v] * 12;
             const float c = (t[a] + t[4 + a] + t[8 + a]) * (1.0f / 3.0f);
-            cen[3 * v + a] = (c == c && c > -1.0e30f && c < 1.0e30f) ? c : 0.0f;
+            pts[6 * v + a] = finite(c) ? c : 0.0f;
+            if (finite(c)) { blo[a] = std::min(blo[a], c); bhi[a] = std::max(bhi[a], c); }
         }
+        const float e1[3] = {t[4] - t[0], t[5] - t[1], t[6] - t[2]}, e2[3] = {t[8] - t[0], t[9] - t[1], t[10] - t[2]};
+        const float nx = e1[1] * e2[2] - e1[2] * e2[1], ny = e1[2] * e2[0] - e1[0] * e2[2], nz = e1[0] * e2[1] - e1[1] * e2[0];
+        const float nl = std::sqrt(nx * nx + ny * ny + nz * nz);
+        const bool ok = finite(nl) && nl > 0.0f;
+        pts[6 * v + 3] = ok ? nx / nl : 0.0f; pts[6 * v + 4] = ok ? ny / nl : 0.0f; pts[6 * v + 5] = ok ? nz / nl : 0.0f;
+    }
+    float ext = 0.0f;
+    for (int a = 0; a < 3; ++a) if (blo[a] <= bhi[a]) ext = std::max(ext, bhi[a] - blo[a]);
+    const float lambda = 0.2f * ext;
+    for (size_t v = 0; v < n; ++v) for (int a = 3; a < 6; ++a) pts[6 * v + a] *= lambda;
     std::vector<uint32_t> order(n);
     for (size_t i = 0; i < n; ++i) order[i] = (uint32_t)i;
     std::vector<std::pair<size_t, size_t>> todo;
@@ -705,13 +726,15 @@ static std::vector<uint32_t> kd_order(const rtgl_context *ctx, const std::vector
         if (m <= (size_t)kMfTileTris) continue;
         const size_t unit = m > group_tris ? group_tris : (m > (size_t)kMfQuadTris ? (size_t)kMfQuadTris : (size_t)kMfTileTris);
         const size_t nl = ((m / 2 + unit - 1) / unit) * unit;           // in [unit, m): m > unit
-        float bl[3] = {3.0e38f, 3.0e38f, 3.0e38f}, bh[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+        const int dims = m > group_tris ? 3 : 6;
+        float bl[6], bh[6];
+        for (int a = 0; a < dims; ++a) { bl[a] = 3.0e38f; bh[a] = -3.0e38f; }
         for (size_t i = lo; i < hi; ++i)
-            for (int a = 0; a < 3; ++a) { const float c = cen[3 * (size_t)order[i] + a]; bl[a] = std::min(bl[a], c); bh[a] = std::max(bh[a], c); }
+            for (int a = 0; a < dims; ++a) { const float c = pts[6 * (size_t)order[i] + a]; bl[a] = std::min(bl[a], c); bh[a] = std::max(bh[a], c); }
         int ax = 0;
-        for (int a = 1; a < 3; ++a) if (bh[a] - bl[a] > bh[ax] - bl[ax]) ax = a;
+        for (int a = 1; a < dims; ++a) if (bh[a] - bl[a] > bh[ax] - bl[ax]) ax = a;
         std::nth_element(order.begin() + lo, order.begin() + lo + nl, order.begin() + hi, [&](uint32_t p, uint32_t q) {
-            const float cp = cen[3 * (size_t)p + ax], cq = cen[3 * (size_t)q + ax];
+            const float cp = pts[6 * (size_t)p + ax], cq = pts[6 * (size_t)q + ax];
             return cp < cq || (cp == cq && p < q);
         });
         todo.emplace_back(lo, lo + nl);
