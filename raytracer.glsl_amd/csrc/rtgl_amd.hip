@@ -683,7 +683,7 @@ static int rebuild_sphere_visits(rtgl_context *ctx)
 // quad of 4 tiles -> group of `group_tris` triangles), so every tile, quad and group of the storage order is one subtree.
 //   * down to the groups the tree splits the triangle CENTROIDS: a group shares one local origin and one set of bounds in the bf16
 //     broad phase (rt_mfma.hpp), whose margin grows with the group's extent;
-//   * inside a group it splits the six-dimensional points (centroid, lambda x unit normal), lambda = a fifth of the mesh's extent: a
+//   * inside a group it splits the six-dimensional points (centroid, lambda x unit normal), lambda = 0.4 x the mesh's extent: a
 //     tile's culling record (rt_mfma.hpp, MfCull) bounds its ten normals by a rectangle, and on a mesh that is coarse against its own
 //     curvature (the 100,000-triangle benchmark field turns by 15 degrees from one cell to the next) ten NEIGHBOURS spread +-33 degrees --
 //     a quarter of all far tiles then fail the certificates on their normals alone.  Ten triangles of similar slope from anywhere in
@@ -714,7 +714,8 @@ static std::vector<uint32_t> kd_order(const rtgl_context *ctx, const std::vector
     }
     float ext = 0.0f;
     for (int a = 0; a < 3; ++a) if (blo[a] <= bhi[a]) ext = std::max(ext, bhi[a] - blo[a]);
-    const float lambda = 0.2f * ext;
+    float lambda = 0.4f * ext;
+    if (const char *e = getenv("RTGL_AMD_KD_LAMBDA")) lambda = (float)atof(e) * ext;      // (tuning: fraction of the mesh's extent)
     for (size_t v = 0; v < n; ++v) for (int a = 3; a < 6; ++a) pts[6 * v + a] *= lambda;
     std::vector<uint32_t> order(n);
     for (size_t i = 0; i < n; ++i) order[i] = (uint32_t)i;
