@@ -892,6 +892,7 @@ static int ensure_wave_buffers(rtgl_context *ctx, uint32_t n0, uint32_t max_boun
             ctx->wb.qt.rng = (uint4 *)p; p += cap * 16; ctx->wb.sort_kr = (uint2 *)p; p += cap * 8; ctx->wb.qt.pixel = (uint32_t *)p;
             // origin cells: 16 per axis of the mesh's box (cubes), 32 for more than four million rays
             ctx->wb.sort_ob = n0 > (4u << 20) ? 5u : 4u;
+            if (const char *e = getenv("RTGL_AMD_SORT_OB")) { const int v = atoi(e); if (v >= 1 && v <= 5) ctx->wb.sort_ob = (uint32_t)v; }      // (tuning)
             ctx->wb.sort_bits = 8u + 3u * ctx->wb.sort_ob;
             if (ctx->sort_bits_alloc < ctx->wb.sort_bits) {
                 if (ctx->d_sort_hist) { HIPCHK(ctx, hipFree(ctx->d_sort_hist)); ctx->d_sort_hist = nullptr; }
