@@ -912,6 +912,9 @@ scan_solo_kernel(SceneView sc, WaveBuffers wb, MfView mf, uint32_t bounce, uint3
     if (lane == 0 && mf.dbg_log) {
         unsigned long long *d = reinterpret_cast<unsigned long long *>(mf.dbg_log) + 16ull * bounce;
         const unsigned long long ts_end = RT_STAMP_NOW();
+#if RT_SOLO_STAMPS == 3
+        const unsigned long long tr_end = __builtin_amdgcn_s_memrealtime();          // (both clocks read before the atomics below, which queue up for microseconds)
+#endif
         atomicAdd(d + 0, ts_end - ts_wave_begin); atomicAdd(d + 1, tt_stage); atomicAdd(d + 2, tt_rays); atomicAdd(d + 3, tt_group);
         atomicAdd(d + 4, tt_steady); atomicAdd(d + 5, tt_park); atomicAdd(d + 6, tt_flush); atomicAdd(d + 7, tt_iters); atomicAdd(d + 8, 1ull);
         atomicAdd(d + 9, tt_tiles);
@@ -923,7 +926,7 @@ scan_solo_kernel(SceneView sc, WaveBuffers wb, MfView mf, uint32_t bounce, uint3
         }
         atomicAdd(d + 11, tt_culled); atomicAdd(d + 12, tt_culled_n);
 #if RT_SOLO_STAMPS == 3
-        atomicAdd(d + 14, __builtin_amdgcn_s_memrealtime() - tr_wave_begin);
+        atomicAdd(d + 14, tr_end - tr_wave_begin);
 #endif
     }
 #endif
