@@ -626,11 +626,12 @@ scan_solo_kernel(SceneView sc, WaveBuffers wb, MfView mf, uint32_t bounce, uint3
         constexpr uint32_t kNone = 0xFFFFFFFFu;
         // (the address is made to look divergent: for a uniform one LLVM's atomic optimizer rewrites the operation into its wave-aggregated
         // form, which is no faster here and longer)
-        // hybrid: six of seven granules in fixed turns (nothing to wait for, every wave knows its next item), every seventh -- spread evenly
+        // hybrid: two of three granules (hybrid_div - 1 of hybrid_div) in fixed turns (nothing to wait for, every wave knows its next item), every third -- spread evenly
         // over the queue, so that the tail looks like the rest -- claimed from the chunk's counter when the wave is through with its
         // turns: with culling an item costs anything between nothing and 128 tiles, and fixed turns alone left the launch waiting for
         // its unluckiest wave (1.5 x the mean wave on bounce 1 of C2, 2.4 x on bounce 4)
-        const uint32_t n_tail = hybrid ? n_gran / 7u : 0u, n_turns = n_gran - n_tail;
+        const uint32_t hdiv = max(wb.hybrid_div, 1u), hturn = max(hdiv - 1u, 1u);      // hybrid: every hdiv-th granule is claimed (1: all of them)
+        const uint32_t n_tail = hybrid ? n_gran / hdiv : 0u, n_turns = n_gran - n_tail;
         const uint32_t n_claimable = hybrid ? n_tail : n_items;
         auto claim = [&](uint32_t seen, uint32_t &lo, uint32_t &end) {
             const uint32_t rem = n_claimable > seen ? n_claimable - seen : 0u;
@@ -646,7 +647,7 @@ scan_solo_kernel(SceneView sc, WaveBuffers wb, MfView mf, uint32_t bounce, uint3
         // from the granule's row (chunk_keep_bits), through the scalar cache.
         const ConstWords keep_k = (ConstWords)(uintptr_t)wb.keep;
         auto item_of = [&](uint32_t k, uint32_t &g, Mask128 &bits) {
-            g = hybrid ? (tail ? 7u * k + 6u : (k / 6u) * 7u + k % 6u) : k; bits = keep_all;
+            g = hybrid ? (tail ? hdiv * k + (hdiv - 1u) : (k / hturn) * hdiv + k % hturn) : k; bits = keep_all;
             if (cull) {
                 if (dynamic) g = items_k[k];
                 bits = chunk_keep_bits(keep_k + (size_t)g * wb.keep_words, tile_begin, n_tiles);

@@ -53,6 +53,7 @@ struct WaveBuffers {
     uint32_t *items;              // kernel 4, culled dynamic launches: per chunk of the scan launch the granules that have anything to scan
     uint32_t *item_counts;        //   ... their number per chunk; items_stride entries are reserved per chunk (cull_items_kernel)
     uint32_t items_stride;
+    uint32_t hybrid_div;          // kernel 4, hybrid work distribution: every hybrid_div-th granule is claimed, the others are taken in turns
     uint32_t *plan_prefix;        // kernel 4, planned work distribution of a culled launch: per chunk the inclusive prefix sum of the items' costs over
     uint32_t plan_stride;         //   the granules (plan_stride entries per chunk), the chunks' totals and where each chunk starts on the cost line
     uint32_t *plan_total;         //   (scan_plan_kernel, scan_plan_base_kernel; rt_scan.hpp)

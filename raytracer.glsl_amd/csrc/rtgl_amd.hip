@@ -905,6 +905,8 @@ static int ensure_wave_buffers(rtgl_context *ctx, uint32_t n0, uint32_t max_boun
             for (int a = 0; a < 3; ++a) ctx->wb.sort_lo[a] = ctx->mesh_lo[a] - 0.01f * ext;
             ctx->wb.sort_scale = (float)(1u << ctx->wb.sort_ob) / ext;
         }
+        ctx->wb.hybrid_div = 3u;          // (measured on C2 / C5: every 7th claimed 707 / 752 Mpaths/s, every 3rd 720 / 776, every 2nd 724 / 777, all of them 677 / 737)
+        if (const char *e = getenv("RTGL_AMD_HYBRID_DIV")) { const int v = atoi(e); if (v >= 1 && v <= 64) ctx->wb.hybrid_div = (uint32_t)v; }      // (tuning)
         ctx->wb.items = reinterpret_cast<uint32_t *>(ctx->d_items); ctx->wb.item_counts = reinterpret_cast<uint32_t *>(ctx->d_items);     // (allocated by the first culled launch)
         ctx->wb.cand = ctx->d_cand;
         ctx->wb.cand_counts = reinterpret_cast<uint32_t *>(ctx->d_cand + (size_t)ctx->cand_regions * ctx->cand_region_pairs);
