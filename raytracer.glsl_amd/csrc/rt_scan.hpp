@@ -476,6 +476,7 @@ scan_solo_kernel(SceneView sc, WaveBuffers wb, MfView mf, uint32_t bounce, uint3
     extern __shared__ uint4 lds_tiles[];                      // the chunk's A tiles, [quad][tile][panel][row]
     __shared__ uint2 lds_queue[kWaves * Cfg::kQueue];        // per-wave survivor queue, entry = (lane | tile in chunk << 8, 20-bit mask: bit 5 s + u = triangle u of the lane's half survived for ray set s)
     __shared__ uint32_t lds_pick;                             // the chunk the block scans next
+    __shared__ uint32_t lds_ring[kWaves * 16u];              // per wave: the granules of its last 16 items (queue entries name their item by its turn in this ring)
 #ifdef RT_SOLO_STAMPS
 #if RT_SOLO_STAMPS == 3
     const unsigned long long tr_wave_begin = __builtin_amdgcn_s_memrealtime();
@@ -682,6 +683,45 @@ scan_solo_kernel(SceneView sc, WaveBuffers wb, MfView mf, uint32_t bounce, uint3
             if (dynamic && k >= hi) claim(hi, k, hi);          // (dynamic: the batch is used up)
             if (hybrid && k >= hi) { if (tail) claim(hi, k, hi); else { tail = true; step = 1u; claim(0u, k, hi); } }
         };
+        // The wave's survivor queue lives across its items of this chunk: an entry names its item by the item's turn in a ring of 16
+        // granules, and the queue is handed over when it is full, when the ring is about to wrap, and behind the chunk's last item --
+        // not behind every item (that was 7 % of a wave's time on bounce 1 of C2 and 20-40 % on the late bounces, whose items keep a
+        // handful of tiles each).
+        uint32_t qn = 0, seq = 0, seq_flushed = 0;              // wave-uniform
+        uint32_t *const ring = lds_ring + wave * 16;
+        auto flush = [&]() {
+            // Every (queue entry, ray set) with a non-empty 5-bit mask becomes one record (queue slot of the ray, storage position of
+            // the lane's first triangle << 5 | mask), appended densely to the wave's region (ballot + prefix count per ray set), fire
+            // and forget; the narrow phase expands the masks and maps storage position -> visit index.  What does not fit gets its
+            // exact tests right here, so the result never depends on the buffer size.  `appended` is 64 bits wide: a degenerate
+            // scene (NaN bounds: every pair survives) can exceed 2^32 records per wave.
+            for (uint32_t i0 = 0; i0 < qn; i0 += 64u) {
+                const uint32_t i = i0 + (uint32_t)lane;
+                const uint2 e = i < qn ? queue[i] : make_uint2(0u, 0u);
+                const uint32_t ln = e.x & 63u, pos5 = v_chunk_begin + ((e.x >> 8) & 127u) * kMfTileTris + 5u * (ln >> 5);
+                const uint32_t slot0 = ring[(e.x >> 16) & 15u] * 128u;
+                if (kCount) c_cand_lane += (unsigned long long)__popc(e.y);
+                const uint32_t bits = (debug_skip_exact == 0 || debug_skip_exact == 3) ? e.y : 0u;
+#pragma unroll
+                for (int s = 0; s < S; ++s) {
+                    uint32_t um = (bits >> (5 * s)) & 31u;
+                    const unsigned long long m = __builtin_amdgcn_ballot_w64(um != 0u);
+                    const unsigned long long at = appended + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                    const uint32_t slot = slot0 + (uint32_t)(s * 32) + (ln & 31u);
+                    if (um != 0u) {
+                        if (at < (unsigned long long)wb.cand_region) store_through(reinterpret_cast<unsigned long long *>(cand + at), (unsigned long long)slot | ((unsigned long long)((pos5 << 5) | um) << 32));
+                        else
+                            while (um) {
+                                const uint32_t pos = pos5 + (uint32_t)__builtin_ctz(um);
+                                um &= um - 1u;
+                                if (pos < v_chunk_end) exact_and_merge_at(mf, qin, best, slot, pos);
+                            }
+                    }
+                    appended += (unsigned long long)__popcll(m);
+                }
+            }
+            qn = 0; seq_flushed = seq;
+        };
         while (k < hi) {
             RT_STAMP(ts_iter);
             uint32_t g; Mask128 keep;
@@ -697,6 +737,10 @@ scan_solo_kernel(SceneView sc, WaveBuffers wb, MfView mf, uint32_t bounce, uint3
                 advance();
                 continue;
             }
+            if (seq - seq_flushed >= 15u) flush();              // (the ring is about to wrap)
+            if (lane == 0) ring[seq & 15u] = g;
+            const uint32_t item_tag = (seq & 15u) << 16;
+            ++seq;
             MfRay ray[S];
             if constexpr (W == 1) {
                 if (ray_k != k) fetch_rays(g, nxt_a, nxt_b);
@@ -705,40 +749,6 @@ scan_solo_kernel(SceneView sc, WaveBuffers wb, MfView mf, uint32_t bounce, uint3
                 // the next item's rays travel while this one is scanned (one wave per SIMD: nothing else would hide the round trip)
                 if (succ != kNone && m128_any(rec_keep)) { fetch_rays(rec_g, nxt_a, nxt_b); ray_k = succ; }
             }
-
-            uint32_t qn = 0;                                    // wave-uniform
-            auto flush = [&]() {
-                // Every (queue entry, ray set) with a non-empty 5-bit mask becomes one record (queue slot of the ray, storage position of
-                // the lane's first triangle << 5 | mask), appended densely to the wave's region (ballot + prefix count per ray set), fire
-                // and forget; the narrow phase expands the masks and maps storage position -> visit index.  What does not fit gets its
-                // exact tests right here, so the result never depends on the buffer size.  `appended` is 64 bits wide: a degenerate
-                // scene (NaN bounds: every pair survives) can exceed 2^32 records per wave.
-                for (uint32_t i0 = 0; i0 < qn; i0 += 64u) {
-                    const uint32_t i = i0 + (uint32_t)lane;
-                    const uint2 e = i < qn ? queue[i] : make_uint2(0u, 0u);
-                    const uint32_t ln = e.x & 63u, pos5 = v_chunk_begin + (e.x >> 8) * kMfTileTris + 5u * (ln >> 5);
-                    if (kCount) c_cand_lane += (unsigned long long)__popc(e.y);
-                    const uint32_t bits = debug_skip_exact == 0 ? e.y : 0u;
-#pragma unroll
-                    for (int s = 0; s < S; ++s) {
-                        uint32_t um = (bits >> (5 * s)) & 31u;
-                        const unsigned long long m = __builtin_amdgcn_ballot_w64(um != 0u);
-                        const unsigned long long at = appended + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                        const uint32_t slot = wave_slot0 + (uint32_t)(s * 32) + (ln & 31u);
-                        if (um != 0u) {
-                            if (at < (unsigned long long)wb.cand_region) store_through(reinterpret_cast<unsigned long long *>(cand + at), (unsigned long long)slot | ((unsigned long long)((pos5 << 5) | um) << 32));
-                            else
-                                while (um) {
-                                    const uint32_t pos = pos5 + (uint32_t)__builtin_ctz(um);
-                                    um &= um - 1u;
-                                    if (pos < v_chunk_end) exact_and_merge_at(mf, qin, best, slot, pos);
-                                }
-                        }
-                        appended += (unsigned long long)__popcll(m);
-                    }
-                }
-                qn = 0;
-            };
 
             u32x4 B0, B1, B2, B3;                               // B operands (K layout: see MfView) and thresholds of the four ray sets
             float th0, th1, th2, th3;
@@ -755,7 +765,7 @@ scan_solo_kernel(SceneView sc, WaveBuffers wb, MfView mf, uint32_t bounce, uint3
                 const unsigned long long m = __builtin_amdgcn_ballot_w64(mask != 0u);
                 uint32_t pre = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
                 asm volatile("" : "+v"(pre));                   // (keeps the prefix count out of a branch on "any lane active")
-                queue[mask ? qn + pre : Cfg::kQueue - 1u] = make_uint2((uint32_t)lane | (tile << 8), mask);
+                queue[mask ? qn + pre : Cfg::kQueue - 1u] = make_uint2((uint32_t)lane | (tile << 8) | item_tag, mask);
                 qn += (uint32_t)__popcll(m);
                 if (qn >= Cfg::kDrain) flush();
             };
@@ -899,14 +909,14 @@ scan_solo_kernel(SceneView sc, WaveBuffers wb, MfView mf, uint32_t bounce, uint3
                 RT_STAMP_ADD(tt_steady, ts_g0, ts_g2);
             }
             RT_STAMP(ts_f0);
-            flush();
             advance();
             RT_STAMP(ts_f1);
             RT_STAMP_ADD(tt_flush, ts_f0, ts_f1);
 #ifdef RT_SOLO_STAMPS
-            tt_iters++; tt_tiles += n_tiles;
+            tt_iters++; tt_tiles += m128_popc(keep);          // (tiles the item actually scanned)
 #endif
         }
+        flush();                                               // what the wave's last items of this chunk left in its queue
         if (!dynamic && !planned) break;                       // static: a block stays with the chunk it started on
     }
 #ifdef RT_SOLO_STAMPS
