@@ -104,8 +104,8 @@ def main():
     ap.add_argument("--frame-batch", type=int, default=1, help="opt-in (rtgl option frame_batch): trace this many consecutive frames in one set of launches; the image "
                     "(and the gather at N > 1) then follows every batch instead of every frame, bit-identical; disables the per-launch kernel timing")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--batched-extra", choices=("auto", "on", "off"), default="auto", help="the second, separately reported region (2 x N frames per set of launches): "
-                    "auto = only at N > 1, so that a profile of the default single-GPU command holds the launches of the `value` region alone")
+    ap.add_argument("--batched-extra", choices=("auto", "on", "off"), default="auto", help="the second, separately reported region (frame_batch = 8, or 2 x N at N > 4, frames per set "
+                    "of launches; reported under `frame_batched`, never as `value`): auto = on; the profiling scripts pass `off` so that a profile holds the launches of the `value` region alone")
     ap.add_argument("--sync-each-frame", action="store_true", help="diagnostic: host waits for every frame")
     ap.add_argument("--no-kernel-timing", action="store_true", help="diagnostic: no HIP events around the scan launches")
     ap.add_argument("--cpu-rows", type=int, default=1080, help="rows of the frame the CPU baseline renders (8-row strips, uniformly strided): 1080 = the whole C2 frame, ~10 s on 16 threads")
@@ -224,9 +224,10 @@ def main():
     # A second region, reported beside `value`, never as it: the same workload with 2 x N (at most 16) frames traced per set of launches (option
     # "frame_batch", DESIGN.md 7: bit-identical image; the image -- and at N > 1 the gather -- follows every batch instead of every frame).
     batched = None
-    if args.frame_batch == 1 and (args.batched_extra == "on" or (args.batched_extra == "auto" and world > 1)) and args.steps >= 8 and not args.sync_each_frame and not shared_device:
+    if args.frame_batch == 1 and args.batched_extra in ("on", "auto") and args.steps >= 8 and not args.sync_each_frame and not shared_device:
         try:                                               # (whatever happens here must not cost the line its `value`)
-            B = min(2 * world, 16)                         # a rank then launches what two whole frames are to a single GPU
+            B = min(max(8, 2 * world), 16, args.steps // 8 * 8 if args.steps < 16 else 16)   # eight frames per set of launches (a rank of N > 4: what two whole frames are to a single GPU)
+            B = max(B, 2)
             kb = args.steps // B * B
             ctx.set_option("kernel_timing", 0)
             ctx.set_option("frame_batch", B)
@@ -252,8 +253,9 @@ def main():
             batch_now[0] = 1
             batched = {"frame_batch": B, "steps": kb, "ms_per_step": dtb / kb * 1e3, "unit": "Mpaths/s",
                        "value": (W // 8 * 8) * (H // 8 * 8) * base.samples * kb / dtb / 1e6,
-                       "note": f"same frames, {B} traced per set of launches (rtgl option frame_batch, opt-in, bit-identical); the image and the gather follow every batch, "
-                               "not every frame; measured after the region `value` comes from, same barriers"}
+                       "note": f"OPT-IN, not the default and not `value`: the same frames, {B} traced per set of launches (rtgl option frame_batch, bit-identical image); the image "
+                               "and the gather follow every batch, not every frame (a display every B-th frame); measured after the region `value` comes from, same barriers.  "
+                               "More rays per launch fill the small late-bounce kernels and the direction / origin bins of the culling"}
         except Exception as e:                              # noqa: BLE001
             batched = {"error": f"{type(e).__name__}: {e}"}
             ctx.set_option("frame_batch", 1)
