@@ -119,16 +119,26 @@ __global__ void __launch_bounds__(64) prepare_mfma_kernel(const float4 *__restri
         for (int k = 0; k < 3; ++k) { float4 p = vertices[3 * (size_t)tri + k]; w[k] = mk(p.x, p.y, p.z); wl[k] = w[k] - c; }
         const uint32_t in_group = v - v_begin, tile = in_group / kMfTileTris, tt = in_group % kMfTileTris;
         const int h = (int)(tt / 5), u = (int)(tt % 5);
+        const float cn = __builtin_sqrtf(dot3(c, c));
         for (int k = 0; k < 3; ++k) {
             const int a = (k + 1) % 3;                                   // edge k runs from vertex k to vertex a
             const f3 e = w[a] - w[k];
             const f3 ml = cross3(wl[a], wl[k]);
-            E = fmaxf(E, __builtin_sqrtf(dot3(e, e)));
-            Ml = fmaxf(Ml, __builtin_sqrtf(dot3(ml, ml)));
-            P = fmaxf(P, __builtin_sqrtf(dot3(wl[a], wl[a])) * __builtin_sqrtf(dot3(wl[k], wl[k])));
-            Pw = fmaxf(Pw, __builtin_sqrtf(dot3(w[a], w[a])) * __builtin_sqrtf(dot3(w[k], w[k])));
+            // Row scale (round 3).  All rows of a group are compared with ONE threshold per ray, so the threshold has to cover the
+            // row that needs most: unscaled, a group with one long edge (E) taxed every short edge with E's bf16 error, E / |e| times
+            // what it needed -- on a fine mesh with steep faces (100k benchmark field: edges 0.1 .. 0.65) survivors were ten times
+            // the hits.  Each row is multiplied by a power of two sc ~ 1 / (|e| + 2^-13 pw), pw = |v_a||v_k| + |e||c| (the edge's
+            // share of the reference's own rounding): exact in binary floating point, so the derivation of mf_margin holds for the
+            // scaled row as it stands, with the group's bounds taken over the SCALED quantities; the two dominant terms of the
+            // margin, 2^-8 sc|e||cv'| and 2^-20 sc pw |d|, then cost every edge about the same fraction of its own length.
+            const float el = __builtin_sqrtf(dot3(e, e)), mll = __builtin_sqrtf(dot3(ml, ml));
+            const float pl = __builtin_sqrtf(dot3(wl[a], wl[a])) * __builtin_sqrtf(dot3(wl[k], wl[k]));
+            const float pw = __builtin_sqrtf(dot3(w[a], w[a])) * __builtin_sqrtf(dot3(w[k], w[k])) + el * cn;
+            const float want = 1.0f / (el + 1.220703125e-4f * pw);
+            float sc = (want > 1.0e-12f && want < 1.0e12f) ? __uint_as_float(__float_as_uint(want) & 0x7f800000u) : 1.0f;      // 2^floor(log2 want); degenerate edges: 1
+            E = fmaxf(E, sc * el); Ml = fmaxf(Ml, sc * mll); P = fmaxf(P, sc * pl); Pw = fmaxf(Pw, sc * pw);
             __bf16 *row = rows + ((size_t)tile * 64 + mf_row(3 * u + k, h)) * 8, *row1 = row + 32 * 8;
-            const float ev[3] = {e.x, e.y, e.z}, mv[3] = {ml.x, ml.y, ml.z};
+            const float ev[3] = {sc * e.x, sc * e.y, sc * e.z}, mv[3] = {sc * ml.x, sc * ml.y, sc * ml.z};
             __bf16 mh[3];
             for (int i = 0; i < 3; ++i) {
                 const __bf16 eh = (__bf16)ev[i]; mh[i] = (__bf16)mv[i];
@@ -146,8 +156,7 @@ __global__ void __launch_bounds__(64) prepare_mfma_kernel(const float4 *__restri
     G.cx = c.x; G.cy = c.y; G.cz = c.z;
     const float nanv = __builtin_nanf("");
     // Moving the origin to c is exact only for e = v_a - v_k; with the rounded e the two forms of F differ by
-    // d.((e_exact - e) x c) <= 2^-24 |e||c||d|: folded into Pw (the 2^-20 "world" term of mf_margin)
-    Pw = Pw + E * __builtin_sqrtf(dot3(c, c));
+    // d.((e_exact - e) x c) <= 2^-24 |e||c||d|: part of every edge's pw above (the 2^-20 "world" term of mf_margin)
     G.E = bad ? nanv : E * 1.001f; G.Ml = bad ? nanv : Ml * 1.001f; G.Pw = bad ? nanv : Pw * 1.001f;   // NaN bounds: nothing is ever rejected
     G.P = bad ? nanv : P * 1.001f; G.pad1 = 0.0f;
     groups[g] = G;
