@@ -85,7 +85,7 @@ __device__ __forceinline__ float wave_min(float x) { for (int off = 32; off > 0;
 
 __global__ void __launch_bounds__(64) prepare_mfma_kernel(const float4 *__restrict__ vertices, const uint32_t *__restrict__ visit_tri,
                                                           const uint32_t *__restrict__ order, uint32_t n_visits, uint32_t n_groups,
-                                                          uint32_t group_quads, MfGroup *__restrict__ groups, uint4 *__restrict__ A)
+                                                          uint32_t group_quads, MfGroup *__restrict__ groups, uint4 *__restrict__ A, float row_gamma)
 {
     const uint32_t g = blockIdx.x, lane = threadIdx.x;
     if (g >= n_groups) return;
@@ -134,7 +134,7 @@ __global__ void __launch_bounds__(64) prepare_mfma_kernel(const float4 *__restri
             const float el = __builtin_sqrtf(dot3(e, e)), mll = __builtin_sqrtf(dot3(ml, ml));
             const float pl = __builtin_sqrtf(dot3(wl[a], wl[a])) * __builtin_sqrtf(dot3(wl[k], wl[k]));
             const float pw = __builtin_sqrtf(dot3(w[a], w[a])) * __builtin_sqrtf(dot3(w[k], w[k])) + el * cn;
-            const float want = 1.0f / (el + 1.220703125e-4f * pw);
+            const float want = 1.0f / (el + row_gamma * pw);      // (row_gamma = 2^-13 unless tuned)
             float sc = (want > 1.0e-12f && want < 1.0e12f) ? __uint_as_float(__float_as_uint(want) & 0x7f800000u) : 1.0f;      // 2^floor(log2 want); degenerate edges: 1
             E = fmaxf(E, sc * el); Ml = fmaxf(Ml, sc * mll); P = fmaxf(P, sc * pl); Pw = fmaxf(Pw, sc * pw);
             __bf16 *row = rows + ((size_t)tile * 64 + mf_row(3 * u + k, h)) * 8, *row1 = row + 32 * 8;

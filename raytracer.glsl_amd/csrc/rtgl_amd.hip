@@ -808,7 +808,7 @@ static int rebuild_triangles(rtgl_context *ctx)
         HIPCHK(ctx, hipMalloc((void **)&ctx->d_mf_A, a_bytes));
         HIPCHK(ctx, hipMemsetAsync(ctx->d_mf_A, 0, a_bytes, ctx->stream));
         hipLaunchKernelGGL(prepare_mfma_kernel, dim3(ctx->n_mf_groups), dim3(64), 0, ctx->stream, ctx->d_vertices, d_visit,
-                           ctx->d_mf_order, ctx->n_tri_visits, ctx->n_mf_groups, ctx->mf_group_quads, ctx->d_mf_groups, ctx->d_mf_A);
+                           ctx->d_mf_order, ctx->n_tri_visits, ctx->n_mf_groups, ctx->mf_group_quads, ctx->d_mf_groups, ctx->d_mf_A, getenv("RTGL_AMD_ROW_GAMMA") ? (float)atof(getenv("RTGL_AMD_ROW_GAMMA")) : 1.220703125e-4f);
         HIPCHK(ctx, hipGetLastError());
         // packet-culling records, one per tile of the storage order (all-zero records -- unusable -- behind the last one)
         const uint32_t n_tiles_all = ctx->n_mf_groups * ctx->mf_group_quads * (uint32_t)kMfQuadTiles, n_tiles_alloc = n_tiles_all + 128u;
