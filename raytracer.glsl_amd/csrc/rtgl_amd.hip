@@ -1037,7 +1037,9 @@ static int launch_intersect_solo(rtgl_context *ctx, const SceneView &sc, uint32_
     const uint32_t chunks = (real_quads + chunk_quads - 1) / chunk_quads;
     // (auto: the camera-ray bounce of a small mesh keeps its fixed turns -- almost every item is empty there and a claimed tail only adds
     // round trips: 74 us against 168 on C2; the binned bounces take the hybrid form: 660 -> 589, 553 -> 499 us)
-    const int dist = (ctx->opt_scan_dynamic == 0 && bounce == 0 && solo_dynamic(ctx) == 3) ? 0 : solo_dynamic(ctx), dynamic = dist == 1;
+    const int cull = ctx->opt_cull == 2 || (ctx->opt_cull >= 1 && bounce == 0) || (ctx->opt_cull == 3 && binned);
+    // (unculled launches have items of equal cost: fixed turns are balanced there and a claimed tail only adds round trips)
+    const int dist = (ctx->opt_scan_dynamic == 0 && (bounce == 0 || !cull) && solo_dynamic(ctx) == 3) ? 0 : solo_dynamic(ctx), dynamic = dist == 1;
     // one block per CU (forced by the LDS request); fewer when there is not an item per wave.  Static: the same number of blocks on
     // every chunk.
     uint32_t blocks = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(((uint64_t)est_gran * chunks + waves - 1) / waves, (uint64_t)ctx->n_cus));
@@ -1066,7 +1068,7 @@ static int launch_intersect_solo(rtgl_context *ctx, const SceneView &sc, uint32_
     }
     // packet culling pays where the 128 rays of a granule are coherent: the camera rays, and every queue that was binned (option "cull":
     // 0 never, 1 bounce 0, 2 every bounce as the queues come, 3 (default) bounce 0 and the binned bounces)
-    const int cull = ctx->opt_cull == 2 || (ctx->opt_cull >= 1 && bounce == 0) || (ctx->opt_cull == 3 && binned);
+
     if (cull) {
         // camera-ray bounce of a single frame: the bits of an earlier frame of the same camera, image and scene, if there are any
         float ro_add = 0.0f, sigma_add = 0.0f;
