@@ -3,8 +3,8 @@
 Round 2 found that every build whose matrix-core scan kernel SPILLED vector registers produced, rarely, wrong frames when several
 path-tracing pipelines ran on one device at the same time, and that no spill-free build ever did (the mechanism is not
 established).  Spills come and go with small source changes, so they are pinned here: the static variants of `scan_solo_kernel`
-(everything up to 41k triangles, and every rank of a multi-GPU run) must not spill a vector register nor use scratch; the dynamic
-(claiming, opt-in since round 3) two-wave variant may spill in its prologue only (bounded here), and every variant must fit its register budget: 256 per wave with two
+(everything up to 41k triangles, and every rank of a multi-GPU run) must not spill a vector register nor use scratch; the claiming
+two-wave variants (culled bounces since round 3) may spill in their prologue only (bounded here: 2 registers shipping, 12 counting), and every variant must fit its register budget: 256 per wave with two
 waves per SIMD, the whole file (512) with one.
 """
 import os
@@ -51,16 +51,19 @@ def test_all_sixteen_scan_variants_are_built(resource_report):
 
 
 def test_static_and_planned_scan_variants_spill_no_vector_register(resource_report):
-    """static turns (kDist 0) and planned intervals (kDist 2, the default of every launch since round 3, C4 included)"""
+    """static turns (kDist 0: bounce 0 and every unculled launch) and planned intervals (kDist 2, an option)"""
     for (count, waves, dyn), r in scan_variants(resource_report).items():
         if dyn in (0, 2):
             assert r["VGPRs Spill"] == 0 and r["ScratchSize"] == 0, f"scan_solo_kernel<count={count}, W={waves}, kDist={dyn}> spills: {r}"
 
 
 def test_dynamic_scan_variants_spill_at_most_a_prologue(resource_report):
+    """claimed items (kDist 1: C4's culled bounces) and turns + a claimed tail (kDist 3: the culled bounces below 1024 quads).  The shipping
+    builds (counters off) keep their round-3 figures, 2 and 0; the counting builds (diagnostics: `counters` in the context options) carry
+    two 64-bit tallies more and may spill a few more registers in the same prologue."""
     for (count, waves, dyn), r in scan_variants(resource_report).items():
         if dyn in (1, 3):
-            limit = 0 if waves == 1 else 8
+            limit = 0 if waves == 1 else (12 if count else (2 if dyn == 1 else 0))
             assert r["VGPRs Spill"] <= limit, f"scan_solo_kernel<count={count}, W={waves}, dynamic> spills {r['VGPRs Spill']} vector registers (limit {limit})"
 
 
