@@ -68,9 +68,17 @@ struct WaveBuffers {
     RayQueue qt;                  // staging queue (a third queue)
     uint2 *sort_kr;               // per staging slot: (bin key, rank inside the bin)
     uint32_t *sort_hist;          // rays per bin -> first slot of the bin (sort_prefix_kernel); 2^sort_bits entries + one block sum per 4096
-    uint32_t sort_bits;           // key = direction bin (8 bits: 16 x 16 octahedral cells in Morton order) << 3 sort_ob | origin cell (Morton, sort_ob bits per axis)
+    uint32_t sort_bits;           // key = direction bin (8 bits: 16 x 16 octahedral cells in Morton order) << 3 sort_ob | origin word (3 sort_ob bits)
     uint32_t sort_ob;
-    float sort_lo[3], sort_scale; // origin cell = (o - sort_lo) * sort_scale, clamped to [0, 2^sort_ob)
+    // origin word = [outside flag][3 sort_ob - 1 cell bits].  Inside the mesh's box (+ one cell): cells of the box, the bits dealt to the
+    // axes by extent (a flat mesh spends none on its thin axis) and interleaved longest-cell-first.  Outside (the ground, the spheres: at
+    // C2 58 % of the rays entering bounce 2): 16 cells per axis whose size doubles with the distance from the box's centre -- clamped
+    // into the box's border cells those rays used to blow up the bounds of every granule there.
+    float sort_lo[3], sort_inv_cell[3];        // inside: cell_a = (o_a - lo_a) * inv_cell_a, clamped
+    float sort_in_lo[3], sort_in_hi[3];        // the inside test
+    float sort_cen[3], sort_inv_unit;          // outside: j = floor(log2(1 + |o_a - cen_a| * inv_unit)), clamped to 7; cell = 8 + j or 7 - j
+    uint32_t sort_in_bits, sort_out_bits;      // bits per axis, 4 bits each (x | y << 4 | z << 8)
+    uint32_t sort_in_order, sort_out_order;    // the axis of every key bit from the top, 2 bits each
     float4 *batch_rad;            // frame batching (option "frame_batch"): the paths of B consecutive frames travel through ONE set of launches;
     uint32_t batch_px;            //   a finished path leaves its radiance in batch_rad[frame slot * batch_px + pixel] (the slot rides in the top
                                   //   four bits of the path's pixel word), resolve_batch_kernel folds the slots into the image in frame order
@@ -668,12 +676,32 @@ __device__ __forceinline__ uint32_t ray_bin_key(const WaveBuffers &wb, f3 o, f3 
     if (d.z < 0.0f) { const float uu = (1.0f - fabsf(v)) * (u < 0.0f ? -1.0f : 1.0f), vv = (1.0f - fabsf(u)) * (v < 0.0f ? -1.0f : 1.0f); u = uu; v = vv; }
     const int iu = min(15, max(0, (int)((u * 0.5f + 0.5f) * 16.0f))), iv = min(15, max(0, (int)((v * 0.5f + 0.5f) * 16.0f)));
     const uint32_t dir = spread2((uint32_t)iu) | (spread2((uint32_t)iv) << 1);
-    const float top = (float)((1u << wb.sort_ob) - 1u);
-    const uint32_t cx = (uint32_t)fminf(fmaxf((o.x - wb.sort_lo[0]) * wb.sort_scale, 0.0f), top);       // (NaN -> 0)
-    const uint32_t cy = (uint32_t)fminf(fmaxf((o.y - wb.sort_lo[1]) * wb.sort_scale, 0.0f), top);
-    const uint32_t cz = (uint32_t)fminf(fmaxf((o.z - wb.sort_lo[2]) * wb.sort_scale, 0.0f), top);
-    const uint32_t cell = (spread3(cx) | (spread3(cy) << 1) | (spread3(cz) << 2)) & ((1u << (3u * wb.sort_ob)) - 1u);
-    return (dir << (3u * wb.sort_ob)) | cell;
+    const uint32_t T = 3u * wb.sort_ob - 1u;
+    const float oa[3] = {o.x, o.y, o.z};
+    const bool inside = o.x >= wb.sort_in_lo[0] && o.x <= wb.sort_in_hi[0] && o.y >= wb.sort_in_lo[1] && o.y <= wb.sort_in_hi[1] && o.z >= wb.sort_in_lo[2] && o.z <= wb.sort_in_hi[2];   // (NaN: outside)
+    const uint32_t bits3 = inside ? wb.sort_in_bits : wb.sort_out_bits, order = inside ? wb.sort_in_order : wb.sort_out_order;
+    uint32_t c[3], left[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const uint32_t nb = (bits3 >> (4 * a)) & 15u;
+        left[a] = nb;
+        if (inside) c[a] = (uint32_t)fminf(fmaxf((oa[a] - wb.sort_lo[a]) * wb.sort_inv_cell[a], 0.0f), (float)((1u << nb) - 1u));
+        else {
+            const float u = fminf(fabsf(oa[a] - wb.sort_cen[a]) * wb.sort_inv_unit, 1.0e6f);                 // (NaN -> 1e6)
+            const uint32_t j = min(7u, (__float_as_uint(1.0f + u) >> 23) - 127u);
+            c[a] = (oa[a] >= wb.sort_cen[a] ? 8u + j : 7u - j) >> (4u - nb);
+        }
+    }
+    uint32_t cell = 0u;
+    const uint32_t n = left[0] + left[1] + left[2];             // <= T (the outside cells stop at four bits per axis)
+    for (uint32_t i = 0; i < n; ++i) {
+        const uint32_t a = (order >> (2u * i)) & 3u;
+        const uint32_t l = (a == 0u ? left[0] : a == 1u ? left[1] : left[2]) - 1u;
+        const uint32_t v = a == 0u ? c[0] : a == 1u ? c[1] : c[2];
+        cell = (cell << 1) | ((v >> l) & 1u);
+        left[0] = a == 0u ? l : left[0]; left[1] = a == 1u ? l : left[1]; left[2] = a == 2u ? l : left[2];
+    }
+    return (dir << (T + 1u)) | (inside ? 0u : 1u << T) | (cell << (T - n));
 }
 
 template <bool kCount, bool kSort>

@@ -219,7 +219,7 @@ struct rtgl_context {
     void *d_plan = nullptr; size_t plan_capacity = 0;             // planned work distribution of culled scan launches: cost prefix sums per chunk
     void *d_stage = nullptr; size_t stage_capacity = 0;           // ray binning: the staging queue + (key, rank) per slot
     uint32_t *d_sort_hist = nullptr; uint32_t sort_bits_alloc = 0;
-    float mesh_lo[3] = {0.0f, 0.0f, 0.0f}, mesh_ext = 0.0f;       // box of the triangles' finite vertices (origin cells of the bin key)
+    float mesh_lo[3] = {0.0f, 0.0f, 0.0f}, mesh_hi[3] = {0.0f, 0.0f, 0.0f}, mesh_ext = 0.0f;       // box of the triangles' finite vertices (origin cells of the bin key)
     uint2 *d_cand = nullptr; uint32_t cand_regions = 0, cand_region_pairs = 0, cand_region_target = 0; bool cand_fixed = false;
     bool solo_attr_set = false;              // hipFuncAttributeMaxDynamicSharedMemorySize is per device: raised once per context (= per device binding)
     bool group_explicit = false;             // "mf_group_quads" was set through rtgl_set_option
@@ -766,7 +766,7 @@ static int rebuild_triangles(rtgl_context *ctx)
             for (int k = 0; k < 3; ++k)
                 for (int a = 0; a < 3; ++a) { const float c = vx[(size_t)t * 12 + 4 * k + a]; if (c == c && c > -1.0e30f && c < 1.0e30f) { lo[a] = std::min(lo[a], c); hi[a] = std::max(hi[a], c); } }
         ctx->mesh_ext = 0.0f;
-        for (int a = 0; a < 3; ++a) { ctx->mesh_lo[a] = lo[a] <= hi[a] ? lo[a] : 0.0f; if (lo[a] <= hi[a]) ctx->mesh_ext = std::max(ctx->mesh_ext, hi[a] - lo[a]); }
+        for (int a = 0; a < 3; ++a) { ctx->mesh_lo[a] = lo[a] <= hi[a] ? lo[a] : 0.0f; ctx->mesh_hi[a] = lo[a] <= hi[a] ? hi[a] : 0.0f; if (lo[a] <= hi[a]) ctx->mesh_ext = std::max(ctx->mesh_ext, hi[a] - lo[a]); }
     }
     if (ctx->n_tri_visits) {
         uint32_t *d_visit = nullptr;
@@ -839,6 +839,44 @@ static uint32_t solo_regions(const rtgl_context *ctx) { return std::max<uint32_t
 
 static size_t counts_bytes(uint32_t capacity) { return (size_t)(capacity + 1u) * sizeof(uint32_t); }      // ray counts per bounce + the fullest candidate region
 
+// The origin word of the bin key (rt_wavefront.hpp, ray_bin_key): 3 sort_ob - 1 cell bits behind the outside flag.  Inside: every bit goes to
+// the axis whose cells are still the longest (a degenerate axis gets the last ones, which then carry nothing); outside: one bit less for
+// the axis the mesh is thinnest on.
+static void set_bin_cells(rtgl_context *ctx)
+{
+    WaveBuffers &wb = ctx->wb;
+    const uint32_t T = 3u * wb.sort_ob - 1u;
+    const float ext_max = ctx->mesh_ext > 0.0f ? ctx->mesh_ext * 1.02f : 1.0f;
+    float ext[3]; uint32_t bits[3] = {0, 0, 0}, order = 0;
+    for (int a = 0; a < 3; ++a) ext[a] = std::max((ctx->mesh_hi[a] - ctx->mesh_lo[a]) + 0.02f * ext_max, 1.0e-6f * ext_max);
+    for (uint32_t i = 0; i < T; ++i) {
+        int best = 0;
+        for (int a = 1; a < 3; ++a) if (ext[a] / (float)(1u << bits[a]) > ext[best] / (float)(1u << bits[best])) best = a;
+        if (bits[best] >= 10u) for (int a = 0; a < 3; ++a) if (bits[a] < bits[best]) best = a;
+        bits[best]++; order |= (uint32_t)best << (2u * i);
+    }
+    float cell_max = 0.0f;
+    for (int a = 0; a < 3; ++a) {
+        wb.sort_lo[a] = ctx->mesh_lo[a] - 0.01f * ext_max;
+        wb.sort_inv_cell[a] = (float)(1u << bits[a]) / ext[a];
+        if (bits[a]) cell_max = std::max(cell_max, ext[a] / (float)(1u << bits[a]));
+    }
+    for (int a = 0; a < 3; ++a) { wb.sort_in_lo[a] = wb.sort_lo[a] - cell_max; wb.sort_in_hi[a] = wb.sort_lo[a] + ext[a] + cell_max; wb.sort_cen[a] = wb.sort_lo[a] + 0.5f * ext[a]; }
+    if (const char *e = getenv("RTGL_AMD_BIN_SPLIT")) if (atoi(e) == 0) for (int a = 0; a < 3; ++a) { wb.sort_in_lo[a] = -INFINITY; wb.sort_in_hi[a] = INFINITY; }      // (tuning: every origin clamped into the box's cells)
+    wb.sort_in_bits = bits[0] | (bits[1] << 4) | (bits[2] << 8); wb.sort_in_order = order;
+    wb.sort_inv_unit = 8.0f / ext_max;                            // the first outside cell ends a quarter of the half extent from the centre
+    int thin = 0;
+    for (int a = 1; a < 3; ++a) if (ext[a] < ext[thin]) thin = a;
+    uint32_t ob[3] = {0, 0, 0}, oorder = 0;
+    for (uint32_t i = 0; i < T; ++i) {                            // round robin, the thin axis last
+        int best = -1;
+        for (int k = 0; k < 3; ++k) { const int a = (thin + 1 + k) % 3; if (best < 0 || ob[a] < ob[best]) best = a; }
+        if (ob[best] >= 4u) break;                                // (16 cells per axis at most: T <= 12 here)
+        ob[best]++; oorder |= (uint32_t)best << (2u * i);
+    }
+    wb.sort_out_bits = ob[0] | (ob[1] << 4) | (ob[2] << 8); wb.sort_out_order = oorder;
+}
+
 static int ensure_wave_buffers(rtgl_context *ctx, uint32_t n0, uint32_t max_bounce, bool multi_sample)
 {
     if (ctx->counts_capacity < max_bounce + 2) {
@@ -901,9 +939,7 @@ static int ensure_wave_buffers(rtgl_context *ctx, uint32_t n0, uint32_t max_boun
                 ctx->sort_bits_alloc = ctx->wb.sort_bits;
             }
             ctx->wb.sort_hist = ctx->d_sort_hist;
-            const float ext = ctx->mesh_ext > 0.0f ? ctx->mesh_ext * 1.02f : 1.0f;
-            for (int a = 0; a < 3; ++a) ctx->wb.sort_lo[a] = ctx->mesh_lo[a] - 0.01f * ext;
-            ctx->wb.sort_scale = (float)(1u << ctx->wb.sort_ob) / ext;
+            set_bin_cells(ctx);
         }
         ctx->wb.hybrid_div = 3u;          // (measured on C2 / C5: every 7th claimed 707 / 752 Mpaths/s, every 3rd 720 / 776, every 2nd 724 / 777, all of them 677 / 737)
         if (const char *e = getenv("RTGL_AMD_HYBRID_DIV")) { const int v = atoi(e); if (v >= 1 && v <= 64) ctx->wb.hybrid_div = (uint32_t)v; }      // (tuning)
