@@ -865,6 +865,7 @@ static void set_bin_cells(rtgl_context *ctx)
     if (const char *e = getenv("RTGL_AMD_BIN_SPLIT")) if (atoi(e) == 0) for (int a = 0; a < 3; ++a) { wb.sort_in_lo[a] = -INFINITY; wb.sort_in_hi[a] = INFINITY; }      // (tuning: every origin clamped into the box's cells)
     wb.sort_in_bits = bits[0] | (bits[1] << 4) | (bits[2] << 8); wb.sort_in_order = order;
     wb.sort_inv_unit = 8.0f / ext_max;                            // the first outside cell ends a quarter of the half extent from the centre
+    if (const char *e = getenv("RTGL_AMD_BIN_UNIT")) { const float v = (float)atof(e); if (v > 0.0f) wb.sort_inv_unit = v / ext_max; }      // (tuning)
     int thin = 0;
     for (int a = 1; a < 3; ++a) if (ext[a] < ext[thin]) thin = a;
     uint32_t ob[3] = {0, 0, 0}, oorder = 0;
