@@ -172,3 +172,40 @@ def test_camera_ray_keep_bits_are_reused_only_while_they_are_valid(rt, oracle):
     finally:
         del os.environ["RTGL_AMD_NO_CAMERA_KEEP"]
     assert (a.view(np.uint32) == b.view(np.uint32)).all()
+
+
+@pytest.mark.parametrize("shape", ["flat", "line", "far", "speck", "nan_vertex", "cube"])
+def test_bin_key_cells_on_degenerate_mesh_boxes(rt, oracle, shape):
+    """The bin key deals its origin bits to the axes by the extent of the mesh's box and puts the rays that start outside the box into
+    cells of their own (rt_wavefront.hpp, ray_bin_key; rtgl_amd.hip, set_bin_cells).  Queue order must never show in a result: meshes
+    whose box has no extent on one axis or two, lies far from the origin, is a speck, holds a non-finite vertex, or is a cube -- binned
+    queues forced on (`sort_min_rays` 0), three frames, bit for bit against the oracle."""
+    sc = rt.scenes
+    rng = np.random.default_rng(5)
+    n = 400
+    c = rng.uniform([-15, -10, 2], [15, 5, 10], size=(n, 3))
+    tri = c[:, None, :] + rng.normal(size=(n, 3, 3)) * rng.uniform(0.2, 2.5, n)[:, None, None]
+    if shape == "flat": tri[:, :, 2] = 6.0                                   # every vertex in one plane
+    elif shape == "line": tri[:, :, 2] = 6.0; tri[:, :, 1] = tri[:, :1, 1] * 0 + np.linspace(-3, -3, n)[:, None]      # ... on one line of it (degenerate triangles)
+    elif shape == "far": tri = tri + np.array([3.0e4, -2.0e4, 1.0e4])
+    elif shape == "speck": tri = np.array([0.0, -2.0, 5.0]) + (tri - tri.mean((0, 1))) * 1e-3
+    elif shape == "cube": tri = rng.uniform(-6, 6, size=(n, 1, 3)) + np.array([0, -4, 12.0]) + rng.normal(size=(n, 3, 3)) * 0.8
+    v = np.zeros((n, 3, 4), np.float32); v[..., :3] = tri.astype(np.float32); v[..., 3] = rng.choice([0, 3, 5, 7], size=n)[:, None]
+    if shape == "nan_vertex": v[7, 1, 0] = np.nan; v[11, 2, 2] = np.inf
+    spheres = sc.demo_spheres(True)
+    scene = sc.Scene(spheres=spheres, materials=sc.demo_materials(), meshes=sc.make_meshes([(0, n, 0)]), vertices=v.reshape(-1, 4), nodes=sc.single_leaf(len(spheres)), env=sc.sky_cubemap(16))
+    W, H = 200, 120
+    cam = dict(camera_position=(3.0e4, -2.0e4 - 2.0, 1.0e4 - 30.0)) if shape == "far" else {}
+    p0 = sc.params_c2().replace(max_bounce=6, **cam)
+    ctx = rt.host.Context(W, H)
+    ctx.set_option("kernel", 4); ctx.set_option("cull", 3); ctx.set_option("sort_min_rays", 0); ctx.set_option("rng_state", 1)
+    ctx.upload_scene(scene)
+    img_o = np.zeros((H, W, 4), np.float32); g = sc.GlibcRand(9); seeds_o = None
+    for f in range(1, 4):
+        p = p0.replace(frames=f, random=g.rand())
+        ctx.render(p)
+        _, seeds_o = oracle.render(scene, p, img_o, threads=8, want_seeds=True)
+    img_g = ctx.read_image(); seeds_g = ctx.read_rng_state(); ctx.close()
+    neq = (img_g.view(np.uint32) != img_o.view(np.uint32)).any(axis=2)
+    assert not neq.any(), f"{shape}: {int(neq.sum())} pixels differ, first at {np.argwhere(neq)[:4].tolist()}"
+    assert (seeds_g[:H // 8 * 8, :W // 8 * 8] == seeds_o[:H // 8 * 8, :W // 8 * 8]).all()
