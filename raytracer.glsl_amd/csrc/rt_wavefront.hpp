@@ -656,11 +656,6 @@ __global__ void __launch_bounds__(256) intersect_kernel(SceneView sc, WaveBuffer
 // compaction into the next queue (wave ballot + prefix popcount, one atomicAdd per wave).
 // kSort: the survivors go to the staging queue with their bin key and their rank inside the bin (one atomic per ray on the bin's
 // counter: the rays of a wave scatter over hundreds of bins); sort_prefix_kernel + sort_scatter_kernel finish the job.
-__device__ __forceinline__ uint32_t spread3(uint32_t x)        // 10 bits -> every third bit
-{
-    x &= 0x3ffu; x = (x | (x << 16)) & 0x30000ffu; x = (x | (x << 8)) & 0x300f00fu; x = (x | (x << 4)) & 0x30c30c3u; x = (x | (x << 2)) & 0x9249249u;
-    return x;
-}
 __device__ __forceinline__ uint32_t spread2(uint32_t x)        // 4 bits -> every second bit
 {
     x &= 0xfu; x = (x | (x << 2)) & 0x33u; x = (x | (x << 1)) & 0x55u;
