@@ -755,8 +755,20 @@ __global__ void __launch_bounds__(256) shade_kernel(SceneView sc, FrameParams P,
         const uint32_t out_slot = wave_base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
         if (kSort) {
             // (the bin's counter first: its round trip -- a device-scope atomic is performed at the memory side -- runs beside the ray's stores)
+            // Lanes of the wave that share a bin (camera rays off a mirror, neighbours in a binned queue) take their ranks from ONE
+            // atomic: the groups are found with a readlane + ballot per distinct key, the leaders' atomics go out together.
             const uint32_t key = ray_bin_key(wb, s.o, s.d);
-            const uint32_t rank = atomicAdd(wb.sort_hist + key, 1u);
+            uint32_t grp_n = 1u, grp_rank = 0u; int grp_leader = lane;
+            for (unsigned long long todo = __ballot(1); todo;) {
+                const int l = __builtin_ctzll(todo);
+                const uint32_t k0 = (uint32_t)__builtin_amdgcn_readlane((int)key, l);
+                const unsigned long long m = __ballot(key == k0);
+                if (key == k0) { grp_n = (uint32_t)__popcll(m); grp_rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull)); grp_leader = l; }
+                todo &= ~m;
+            }
+            uint32_t base = 0u;
+            if (lane == grp_leader) base = atomicAdd(wb.sort_hist + key, grp_n);
+            const uint32_t rank = (uint32_t)__shfl((int)base, grp_leader) + grp_rank;
             store_ray(qout, out_slot, s);
             store_through(reinterpret_cast<unsigned long long *>(wb.sort_kr + out_slot), (unsigned long long)key | ((unsigned long long)rank << 32));
         } else { store_ray(qout, out_slot, s); store_through(best_out + out_slot, kNoHitKey); }
