@@ -839,13 +839,13 @@ __global__ void __launch_bounds__(256) sort_scatter_kernel(WaveBuffers wb, uint3
         const float4 a = wb.qt.a[slot], b = wb.qt.b[slot], c = wb.qt.c[slot];
         const uint4 g = wb.qt.rng[slot];
         const uint32_t px = wb.qt.pixel[slot];
-        if (to >= n_rays) continue;                          // (cannot happen: the bins hold exactly the staged rays)
+        if (to >= n_rays) { store_through(best_out + slot, kNoHitKey); continue; }      // (cannot happen: the bins hold exactly the staged rays)
         store_through(qout.a + to, a.x, a.y, a.z, a.w);
         store_through(qout.b + to, b.x, b.y, b.z, b.w);
         store_through(qout.c + to, c.x, c.y, c.z, c.w);
         store_through(qout.rng + to, g.x, g.y, g.z, g.w);
         store_through(qout.pixel + to, px);
-        store_through(best_out + to, kNoHitKey);
+        store_through(best_out + slot, kNoHitKey);           // (every slot below n_rays is some thread's own: a coalesced store instead of a sixth scattered one)
     }
 }
 
