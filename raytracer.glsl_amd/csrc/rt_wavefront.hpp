@@ -70,6 +70,7 @@ struct WaveBuffers {
     uint32_t *sort_hist;          // rays per bin -> first slot of the bin (sort_prefix_kernel); 2^sort_bits entries + one block sum per 4096
     uint32_t sort_bits;           // key = direction bin (8 bits: 16 x 16 octahedral cells in Morton order) << 3 sort_ob | origin word (3 sort_ob bits)
     uint32_t sort_ob;
+    uint32_t sort_db, sort_T;     // direction cells per axis = 2^sort_db (4); origin cell bits behind the flag
     // origin word = [outside flag][3 sort_ob - 1 cell bits].  Inside the mesh's box (+ one cell): cells of the box, the bits dealt to the
     // axes by extent (a flat mesh spends none on its thin axis) and interleaved longest-cell-first.  Outside (the ground, the spheres: at
     // C2 58 % of the rays entering bounce 2): 16 cells per axis whose size doubles with the distance from the box's centre -- clamped
@@ -656,9 +657,9 @@ __global__ void __launch_bounds__(256) intersect_kernel(SceneView sc, WaveBuffer
 // compaction into the next queue (wave ballot + prefix popcount, one atomicAdd per wave).
 // kSort: the survivors go to the staging queue with their bin key and their rank inside the bin (one atomic per ray on the bin's
 // counter: the rays of a wave scatter over hundreds of bins); sort_prefix_kernel + sort_scatter_kernel finish the job.
-__device__ __forceinline__ uint32_t spread2(uint32_t x)        // 4 bits -> every second bit
+__device__ __forceinline__ uint32_t spread2(uint32_t x)        // 8 bits -> every second bit
 {
-    x &= 0xfu; x = (x | (x << 2)) & 0x33u; x = (x | (x << 1)) & 0x55u;
+    x &= 0xffu; x = (x | (x << 4)) & 0x0f0fu; x = (x | (x << 2)) & 0x3333u; x = (x | (x << 1)) & 0x5555u;
     return x;
 }
 __device__ __forceinline__ uint32_t ray_bin_key(const WaveBuffers &wb, f3 o, f3 d)
@@ -669,9 +670,10 @@ __device__ __forceinline__ uint32_t ray_bin_key(const WaveBuffers &wb, f3 o, f3 
     const float il = l1 > 0.0f ? 1.0f / l1 : 0.0f;
     float u = d.x * il, v = d.y * il;
     if (d.z < 0.0f) { const float uu = (1.0f - fabsf(v)) * (u < 0.0f ? -1.0f : 1.0f), vv = (1.0f - fabsf(u)) * (v < 0.0f ? -1.0f : 1.0f); u = uu; v = vv; }
-    const int iu = min(15, max(0, (int)((u * 0.5f + 0.5f) * 16.0f))), iv = min(15, max(0, (int)((v * 0.5f + 0.5f) * 16.0f)));
+    const int nd = 1 << wb.sort_db;
+    const int iu = min(nd - 1, max(0, (int)((u * 0.5f + 0.5f) * (float)nd))), iv = min(nd - 1, max(0, (int)((v * 0.5f + 0.5f) * (float)nd)));
     const uint32_t dir = spread2((uint32_t)iu) | (spread2((uint32_t)iv) << 1);
-    const uint32_t T = 3u * wb.sort_ob - 1u;
+    const uint32_t T = wb.sort_T;
     const float oa[3] = {o.x, o.y, o.z};
     const bool inside = o.x >= wb.sort_in_lo[0] && o.x <= wb.sort_in_hi[0] && o.y >= wb.sort_in_lo[1] && o.y <= wb.sort_in_hi[1] && o.z >= wb.sort_in_lo[2] && o.z <= wb.sort_in_hi[2];   // (NaN: outside)
     const uint32_t bits3 = inside ? wb.sort_in_bits : wb.sort_out_bits, order = inside ? wb.sort_in_order : wb.sort_out_order;

@@ -845,7 +845,7 @@ static size_t counts_bytes(uint32_t capacity) { return (size_t)(capacity + 1u) *
 static void set_bin_cells(rtgl_context *ctx)
 {
     WaveBuffers &wb = ctx->wb;
-    const uint32_t T = 3u * wb.sort_ob - 1u;
+    const uint32_t T = wb.sort_T;
     const float ext_max = ctx->mesh_ext > 0.0f ? ctx->mesh_ext * 1.02f : 1.0f;
     float ext[3]; uint32_t bits[3] = {0, 0, 0}, order = 0;
     for (int a = 0; a < 3; ++a) ext[a] = std::max((ctx->mesh_hi[a] - ctx->mesh_lo[a]) + 0.02f * ext_max, 1.0e-6f * ext_max);
@@ -932,7 +932,10 @@ static int ensure_wave_buffers(rtgl_context *ctx, uint32_t n0, uint32_t max_boun
             // origin cells: 16 per axis of the mesh's box (cubes), 32 for more than four million rays
             ctx->wb.sort_ob = n0 > (4u << 20) ? 5u : 4u;
             if (const char *e = getenv("RTGL_AMD_SORT_OB")) { const int v = atoi(e); if (v >= 1 && v <= 5) ctx->wb.sort_ob = (uint32_t)v; }      // (tuning)
+            ctx->wb.sort_db = 4u;
+            if (const char *e = getenv("RTGL_AMD_SORT_DB")) { const int v = atoi(e); if (v >= 2 && v <= 6) ctx->wb.sort_db = (uint32_t)v; }      // (tuning: the bins stay as many)
             ctx->wb.sort_bits = 8u + 3u * ctx->wb.sort_ob;
+            ctx->wb.sort_T = ctx->wb.sort_bits - 1u - 2u * ctx->wb.sort_db;
             if (ctx->sort_bits_alloc < ctx->wb.sort_bits) {
                 if (ctx->d_sort_hist) { HIPCHK(ctx, hipFree(ctx->d_sort_hist)); ctx->d_sort_hist = nullptr; }
                 const size_t bins = (size_t)1 << ctx->wb.sort_bits;
