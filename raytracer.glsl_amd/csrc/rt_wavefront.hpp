@@ -68,6 +68,7 @@ struct WaveBuffers {
     RayQueue qt;                  // staging queue (a third queue)
     uint2 *sort_kr;               // per staging slot: (bin key, rank inside the bin)
     uint32_t *sort_hist;          // rays per bin -> first slot of the bin (sort_prefix_kernel); 2^sort_bits entries + one block sum per 4096
+    uint32_t *sort_hist_other;    // the counters of the NEXT binned bounce: sort_prefix_kernel leaves them zero (two sets take turns; no fill launch per bounce)
     uint32_t sort_bits;           // key = direction bin (8 bits: 16 x 16 octahedral cells in Morton order) << 3 sort_ob | origin word (3 sort_ob bits)
     uint32_t sort_ob;
     uint32_t sort_db, sort_T;     // direction cells per axis = 2^sort_db (4); origin cell bits behind the flag
@@ -828,6 +829,10 @@ __global__ void __launch_bounds__(256) sort_prefix_kernel(WaveBuffers wb)
     for (uint32_t w = 0; w < wave; ++w) base += wsum[w];
 #pragma unroll
     for (int k = 0; k < 4; ++k) store_through(reinterpret_cast<uint4 *>(h) + k, base + c[4 * k], base + c[4 * k + 1], base + c[4 * k + 2], base + c[4 * k + 3]);
+    // the other set of counters (last used two binned bounces ago; its scatter launch has ended): zero for the next binned bounce
+    uint4 *const z = reinterpret_cast<uint4 *>(wb.sort_hist_other + (size_t)blockIdx.x * kSortSeg + threadIdx.x * 16u);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) store_through(z + k, 0u, 0u, 0u, 0u);
 }
 // the rays entering `bounce` (just left in the staging queue by the shade kernel of bounce - 1) to their slots in key order
 __global__ void __launch_bounds__(256) sort_scatter_kernel(WaveBuffers wb, uint32_t bounce)

@@ -218,7 +218,8 @@ struct rtgl_context {
     uint64_t scene_version = 0;
     void *d_plan = nullptr; size_t plan_capacity = 0;             // planned work distribution of culled scan launches: cost prefix sums per chunk
     void *d_stage = nullptr; size_t stage_capacity = 0;           // ray binning: the staging queue + (key, rank) per slot
-    uint32_t *d_sort_hist = nullptr; uint32_t sort_bits_alloc = 0;
+    uint32_t *d_sort_hist = nullptr; uint32_t sort_bits_alloc = 0;      // two sets of bin counters, used in turns
+    int sort_set = 0; uint32_t sort_set_bits = 0; bool sort_sets_clean = false;      // the set the next binned bounce counts in; false: zero both first (fresh, or a frame was abandoned half way)
     float mesh_lo[3] = {0.0f, 0.0f, 0.0f}, mesh_hi[3] = {0.0f, 0.0f, 0.0f}, mesh_ext = 0.0f;       // box of the triangles' finite vertices (origin cells of the bin key)
     uint2 *d_cand = nullptr; uint32_t cand_regions = 0, cand_region_pairs = 0, cand_region_target = 0; bool cand_fixed = false;
     bool solo_attr_set = false;              // hipFuncAttributeMaxDynamicSharedMemorySize is per device: raised once per context (= per device binding)
@@ -939,10 +940,10 @@ static int ensure_wave_buffers(rtgl_context *ctx, uint32_t n0, uint32_t max_boun
             if (ctx->sort_bits_alloc < ctx->wb.sort_bits) {
                 if (ctx->d_sort_hist) { HIPCHK(ctx, hipFree(ctx->d_sort_hist)); ctx->d_sort_hist = nullptr; }
                 const size_t bins = (size_t)1 << ctx->wb.sort_bits;
-                HIPCHK(ctx, hipMalloc((void **)&ctx->d_sort_hist, (bins + bins / kSortSeg) * sizeof(uint32_t)));
-                ctx->sort_bits_alloc = ctx->wb.sort_bits;
+                HIPCHK(ctx, hipMalloc((void **)&ctx->d_sort_hist, 2 * (bins + bins / kSortSeg) * sizeof(uint32_t)));
+                ctx->sort_bits_alloc = ctx->wb.sort_bits; ctx->sort_sets_clean = false;
             }
-            ctx->wb.sort_hist = ctx->d_sort_hist;
+            ctx->wb.sort_hist = ctx->d_sort_hist; ctx->wb.sort_hist_other = ctx->d_sort_hist;      // (set per binned bounce: launch_wavefront)
             set_bin_cells(ctx);
         }
         ctx->wb.hybrid_div = 3u;          // (measured on C2 / C5: every 7th claimed 707 / 752 Mpaths/s, every 3rd 720 / 776, every 2nd 724 / 777, all of them 677 / 737)
@@ -1230,13 +1231,23 @@ static int launch_wavefront(rtgl_context *ctx, const SceneView &sc, const std::v
                 const bool bin_next = ctx->opt_kernel == RTGL_KERNEL_WAVEFRONT_MFMA_SOLO && ctx->opt_cull == 3 && sc.n_tri_visits > 0 && b + 1u < P.max_bounce
                                       && est_next >= (uint32_t)ctx->opt_sort_min_rays;
                 if (bin_next) {
-                    const size_t bins = (size_t)1 << ctx->wb.sort_bits;
-                    HIPCHK(ctx, hipMemsetAsync(ctx->wb.sort_hist, 0, bins * sizeof(uint32_t), ctx->stream));
+                    // two sets of bin counters take turns: sort_prefix_kernel zeroes the one the next binned bounce will count in
+                    const size_t bins = (size_t)1 << ctx->wb.sort_bits, set_words = bins + bins / kSortSeg;
+                    if (!ctx->sort_sets_clean || ctx->sort_set_bits != ctx->wb.sort_bits) {
+                        HIPCHK(ctx, hipMemsetAsync(ctx->d_sort_hist, 0, 2 * set_words * sizeof(uint32_t), ctx->stream));
+                        ctx->sort_set = 0; ctx->sort_set_bits = ctx->wb.sort_bits;
+                    }
+                    ctx->sort_sets_clean = false;              // (true again once this bounce's launches are in the stream)
+                    if (getenv("RTGL_AMD_HIST_FILL")) HIPCHK(ctx, hipMemsetAsync(ctx->d_sort_hist + (size_t)ctx->sort_set * set_words, 0, bins * sizeof(uint32_t), ctx->stream));      // (measurement: the fill launch per bounce that the turns replace)
+                    ctx->wb.sort_hist = ctx->d_sort_hist + (size_t)ctx->sort_set * set_words;
+                    ctx->wb.sort_hist_other = ctx->d_sort_hist + (size_t)(ctx->sort_set ^ 1) * set_words;
                     if (ctx->opt_counters) hipLaunchKernelGGL((shade_kernel<true, true>), shade_grid, dim3(256), 0, ctx->stream, sc, P, im, ctx->wb, b, rng_out, ctx->d_counters);
                     else hipLaunchKernelGGL((shade_kernel<false, true>), shade_grid, dim3(256), 0, ctx->stream, sc, P, im, ctx->wb, b, rng_out, ctx->d_counters);
                     hipLaunchKernelGGL(sort_sums_kernel, dim3((unsigned)(bins / kSortSeg)), dim3(256), 0, ctx->stream, ctx->wb);
                     hipLaunchKernelGGL(sort_prefix_kernel, dim3((unsigned)(bins / kSortSeg)), dim3(256), 0, ctx->stream, ctx->wb);
                     hipLaunchKernelGGL(sort_scatter_kernel, dim3(std::max(1u, std::min((est_next + 255u) / 256u, 16384u))), dim3(256), 0, ctx->stream, ctx->wb, b + 1u);
+                    HIPCHK(ctx, hipGetLastError());
+                    ctx->sort_set ^= 1; ctx->sort_sets_clean = true;
                 } else if (ctx->opt_counters)
                     hipLaunchKernelGGL((shade_kernel<true, false>), shade_grid, dim3(256), 0, ctx->stream, sc, P, im, ctx->wb, b, rng_out, ctx->d_counters);
                 else
@@ -1720,7 +1731,7 @@ extern "C" int rtgl_get_option(rtgl_context *ctx, const char *key, int *value)
         b += (size_t)ctx->n_tri_visits * (sizeof(TriEdges) + sizeof(TriPlane) + 4 + 112) + (size_t)ctx->n_vec4 * 16 + (size_t)ctx->env_faces * ctx->env_w * ctx->env_h * ctx->env_c;
         if (ctx->d_rng) b += (size_t)std::max(ctx->local_rows, 1) * ctx->width * 16;
         b += ctx->batch_capacity * 16;
-        b += ctx->stage_capacity * 76 + (ctx->sort_bits_alloc ? ((size_t)4 << ctx->sort_bits_alloc) : 0);
+        b += ctx->stage_capacity * 76 + (ctx->sort_bits_alloc ? ((size_t)8 << ctx->sort_bits_alloc) : 0);
         *value = (int)((b + (1u << 20) - 1) >> 20);
     }
     else return fail(ctx, RTGL_ERR_INVALID, std::string("unknown option ") + key);
