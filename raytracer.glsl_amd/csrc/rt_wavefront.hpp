@@ -155,13 +155,14 @@ __device__ __forceinline__ void finish_path(const FrameParams &P, const ImageVie
 // Frame batching: the launch of frame f of a batch writes slots [slot_off, slot_off + n0) with pixel_tag = f << 28; only the first stores
 // the batch's ray count (count0 = rays of all its frames; 0: leave the count alone).  A single frame: slot_off = pixel_tag = 0, count0 = n0.
 __global__ void __launch_bounds__(256) generate_rays_kernel(FrameParams P, ImageView im, WaveBuffers wb, uint32_t sample, uint32_t n0, Counters *counters, uint32_t n_counts,
-                                                            uint32_t slot_off, uint32_t pixel_tag, uint32_t count0)
+                                                            uint32_t slot_off, uint32_t pixel_tag, uint32_t count0, uint32_t n_sched)
 {
     // the ray counts of the bounces (and the word behind them) start at zero: cleared here rather than by a memset launch of their own
     // (n_counts = 0: the host has done it); nothing touches them before the first shade kernel
     if (blockIdx.x == 0 && threadIdx.x < n_counts && threadIdx.x > 0u) store_through(wb.counts + threadIdx.x, 0u);
     // queue order = 8x8 pixel blocks, row-major over blocks: neighbouring lanes start as neighbouring pixels
     const uint32_t idx = blockIdx.x * 256u + threadIdx.x;
+    if (idx < n_sched) store_through(wb.sched + idx, 0u);      // the scan launches' work counters of this frame (n_sched = 0: the host has cleared them)
     if (idx >= n0) return;
     if (idx == 0u) {
         if (count0) store_through(wb.counts, count0);

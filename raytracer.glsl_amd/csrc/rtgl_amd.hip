@@ -1196,11 +1196,16 @@ static int launch_wavefront(rtgl_context *ctx, const SceneView &sc, const std::v
     for (uint32_t s = 0; s < P.samples; ++s) {
         const uint32_t n_counts = ctx->counts_capacity + 1u <= 256u ? ctx->counts_capacity + 1u : 0u;      // cleared by generate_rays_kernel's first block
         if (!n_counts) HIPCHK(ctx, hipMemsetAsync(ctx->d_counts, 0, counts_bytes(ctx->counts_capacity), ctx->stream));
-        if (ctx->opt_kernel == RTGL_KERNEL_WAVEFRONT_MFMA_SOLO && ctx->d_sched && (solo_dynamic(ctx) == 1 || solo_dynamic(ctx) == 3))  // the scan launches' work counters (rt_scan.hpp)
-            HIPCHK(ctx, hipMemsetAsync(ctx->d_sched, 0, (size_t)(P.max_bounce + 2) * ctx->wb.sched_stride * sizeof(uint32_t), ctx->stream));
+        // the scan launches' work counters (rt_scan.hpp): cleared by the first threads of generate_rays_kernel where there are enough of them
+        uint32_t n_sched = 0u;
+        if (ctx->opt_kernel == RTGL_KERNEL_WAVEFRONT_MFMA_SOLO && ctx->d_sched && (solo_dynamic(ctx) == 1 || solo_dynamic(ctx) == 3)) {
+            const size_t words = (size_t)(P.max_bounce + 2) * ctx->wb.sched_stride;
+            if (words <= (size_t)gen_grid.x * 256u && !getenv("RTGL_AMD_SCHED_FILL")) n_sched = (uint32_t)words;      // (the variable: measurement of the fill launch this replaces)
+            else HIPCHK(ctx, hipMemsetAsync(ctx->d_sched, 0, words * sizeof(uint32_t), ctx->stream));
+        }
         for (uint32_t f = 0; f < B; ++f)
             hipLaunchKernelGGL(generate_rays_kernel, gen_grid, dim3(256), 0, ctx->stream, frames[f], im, ctx->wb, s, n0_frame,
-                               ctx->opt_counters ? ctx->d_counters : (Counters *)nullptr, f == 0 ? n_counts : 0u, f * n0_frame, B > 1 ? f << 28 : 0u, f == 0 ? n0 : 0u);
+                               ctx->opt_counters ? ctx->d_counters : (Counters *)nullptr, f == 0 ? n_counts : 0u, f * n0_frame, B > 1 ? f << 28 : 0u, f == 0 ? n0 : 0u, f == 0 ? n_sched : 0u);
         bool binned = false;                                 // the queue of the bounce about to be launched was binned
         for (uint32_t b = 0; b < P.max_bounce; ++b) {
             const int key = ctx->opt_wf_mode * 10 + ctx->opt_wf_rays;
