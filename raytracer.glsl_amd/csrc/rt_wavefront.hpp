@@ -68,7 +68,7 @@ struct WaveBuffers {
     RayQueue qt;                  // staging queue (a third queue)
     uint2 *sort_kr;               // per staging slot: (bin key, rank inside the bin)
     uint32_t *sort_hist;          // rays per bin -> first slot of the bin (sort_prefix_kernel); 2^sort_bits entries + one block sum per 4096
-    uint32_t *sort_hist_other;    // the counters of the NEXT binned bounce: sort_prefix_kernel leaves them zero (two sets take turns; no fill launch per bounce)
+    uint32_t *sort_hist_other;    // the counters of the NEXT binned bounce: sort_scatter_kernel leaves them zero (two sets take turns; no fill launch per bounce)
     uint32_t sort_bits;           // key = direction bin (8 bits: 16 x 16 octahedral cells in Morton order) << 3 sort_ob | origin word (3 sort_ob bits)
     uint32_t sort_ob;
     uint32_t sort_db, sort_T;     // direction cells per axis = 2^sort_db (4); origin cell bits behind the flag
@@ -830,10 +830,6 @@ __global__ void __launch_bounds__(256) sort_prefix_kernel(WaveBuffers wb)
     for (uint32_t w = 0; w < wave; ++w) base += wsum[w];
 #pragma unroll
     for (int k = 0; k < 4; ++k) store_through(reinterpret_cast<uint4 *>(h) + k, base + c[4 * k], base + c[4 * k + 1], base + c[4 * k + 2], base + c[4 * k + 3]);
-    // the other set of counters (last used two binned bounces ago; its scatter launch has ended): zero for the next binned bounce
-    uint4 *const z = reinterpret_cast<uint4 *>(wb.sort_hist_other + (size_t)blockIdx.x * kSortSeg + threadIdx.x * 16u);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) store_through(z + k, 0u, 0u, 0u, 0u);
 }
 // the rays entering `bounce` (just left in the staging queue by the shade kernel of bounce - 1) to their slots in key order
 __global__ void __launch_bounds__(256) sort_scatter_kernel(WaveBuffers wb, uint32_t bounce)
@@ -841,6 +837,13 @@ __global__ void __launch_bounds__(256) sort_scatter_kernel(WaveBuffers wb, uint3
     const uint32_t n_rays = wb.counts[bounce];
     const RayQueue qout = (bounce & 1u) ? wb.q[1] : wb.q[0];
     unsigned long long *best_out = (bounce & 1u) ? wb.best[1] : wb.best[0];
+    // the other set of bin counters (last used two binned bounces ago; its scatter launch has ended): zero for the next binned bounce
+    // (4 MB of stores beside this launch's ~200: in sort_prefix_kernel, a launch of 5 us, they cost 3 us)
+    {
+        uint4 *const z = reinterpret_cast<uint4 *>(wb.sort_hist_other);
+        const uint32_t n4 = (uint32_t)(((size_t)1u << wb.sort_bits) / 4u);
+        for (uint32_t w = blockIdx.x * 256u + threadIdx.x; w < n4; w += gridDim.x * 256u) store_through(z + w, 0u, 0u, 0u, 0u);
+    }
     for (uint32_t slot = blockIdx.x * 256u + threadIdx.x; slot < n_rays; slot += gridDim.x * 256u) {
         const uint2 kr = wb.sort_kr[slot];
         const uint32_t to = wb.sort_hist[kr.x] + kr.y;

@@ -1236,7 +1236,7 @@ static int launch_wavefront(rtgl_context *ctx, const SceneView &sc, const std::v
                 const bool bin_next = ctx->opt_kernel == RTGL_KERNEL_WAVEFRONT_MFMA_SOLO && ctx->opt_cull == 3 && sc.n_tri_visits > 0 && b + 1u < P.max_bounce
                                       && est_next >= (uint32_t)ctx->opt_sort_min_rays;
                 if (bin_next) {
-                    // two sets of bin counters take turns: sort_prefix_kernel zeroes the one the next binned bounce will count in
+                    // two sets of bin counters take turns: sort_scatter_kernel zeroes the one the next binned bounce will count in
                     const size_t bins = (size_t)1 << ctx->wb.sort_bits, set_words = bins + bins / kSortSeg;
                     if (!ctx->sort_sets_clean || ctx->sort_set_bits != ctx->wb.sort_bits) {
                         HIPCHK(ctx, hipMemsetAsync(ctx->d_sort_hist, 0, 2 * set_words * sizeof(uint32_t), ctx->stream));
