@@ -930,8 +930,8 @@ static int ensure_wave_buffers(rtgl_context *ctx, uint32_t n0, uint32_t max_boun
             const size_t cap = ctx->stage_capacity;
             ctx->wb.qt.a = (float4 *)p; p += cap * 16; ctx->wb.qt.b = (float4 *)p; p += cap * 16; ctx->wb.qt.c = (float4 *)p; p += cap * 16;
             ctx->wb.qt.rng = (uint4 *)p; p += cap * 16; ctx->wb.sort_kr = (uint2 *)p; p += cap * 8; ctx->wb.qt.pixel = (uint32_t *)p;
-            // origin cells: 16 per axis of the mesh's box (cubes), 32 for more than four million rays
-            ctx->wb.sort_ob = n0 > (4u << 20) ? 5u : 4u;
+            // origin cell bits behind the flag: 11, 14 for more than twelve million rays
+            ctx->wb.sort_ob = n0 > (12u << 20) ? 5u : 4u;            // (C5, 8.3 M rays: 917 Mpaths/s with 4, 909 with 5; C2 in batches of eight, 16.6 M: 2.12 against 2.10 ms per frame)
             if (const char *e = getenv("RTGL_AMD_SORT_OB")) { const int v = atoi(e); if (v >= 1 && v <= 5) ctx->wb.sort_ob = (uint32_t)v; }      // (tuning)
             ctx->wb.sort_db = 4u;
             if (const char *e = getenv("RTGL_AMD_SORT_DB")) { const int v = atoi(e); if (v >= 2 && v <= 6) ctx->wb.sort_db = (uint32_t)v; }      // (tuning: the bins stay as many)
