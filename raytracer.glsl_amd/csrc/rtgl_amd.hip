@@ -1069,10 +1069,11 @@ static int launch_intersect_solo(rtgl_context *ctx, const SceneView &sc, uint32_
     const uint32_t est_gran = (est + Cfg::kRaysPerWave - 1u) / Cfg::kRaysPerWave;
     // A launch has (granules x chunks) work items for its waves, claimed dynamically (rt_scan.hpp).  Late bounces (and every bounce of a
     // rank that owns an eighth of the image) have few granules: cut the triangle range finer, down to 4 quads per chunk, until there are
-    // two items per wave (each item pays its ray and group set-up again, ~20 % at 8 quads, so only as far as needed -- thresholds of 1, 2,
+    // three items per wave (each item pays its ray and group set-up again, ~20 % at 8 quads, so only as far as needed -- thresholds of 1, 2,
     // 4, 8 items per wave measured: 2-4 are best for a rank of four or eight, none matters at N = 1; never more chunks than CUs)
     uint32_t chunk_quads = std::min((uint32_t)ctx->opt_mf_chunk_quads, std::max(real_quads, 1u));
-    while (chunk_quads > 4u && (uint64_t)est_gran * ((real_quads + chunk_quads - 1) / chunk_quads) < 2ull * (uint32_t)ctx->n_cus * waves
+    const uint64_t items_per_wave = getenv("RTGL_AMD_ITEMS_PER_WAVE") ? (uint64_t)std::max(1, atoi(getenv("RTGL_AMD_ITEMS_PER_WAVE"))) : 3ull;      // (tuning; C2: bounce 5's launch 98 -> 89 us with three, bounces 6 and 7 +2 us each; a rank of four or eight, C4, C5: the same with two and three)
+    while (chunk_quads > 4u && (uint64_t)est_gran * ((real_quads + chunk_quads - 1) / chunk_quads) < items_per_wave * (uint32_t)ctx->n_cus * waves
            && (real_quads + chunk_quads / 2 - 1) / (chunk_quads / 2) <= (uint32_t)ctx->n_cus)
         chunk_quads /= 2u;
     const uint32_t chunks = (real_quads + chunk_quads - 1) / chunk_quads;
