@@ -108,18 +108,21 @@ __device__ __forceinline__ void store_through(uint4 *p, uint32_t x, uint32_t y, 
 __device__ __forceinline__ void store_through(uint32_t *p, uint32_t x) { asm volatile("global_store_dword %0, %1, off sc0 sc1" :: "v"(p), "v"(x) : "memory"); }
 __device__ __forceinline__ void store_through(unsigned long long *p, unsigned long long x) { const rt_u2v v = {(uint32_t)x, (uint32_t)(x >> 32)}; asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1\n\ts_nop 1" :: "v"(p), "v"(v) : "memory"); }
 
-__device__ __forceinline__ void store_ray(const RayQueue &q, uint32_t slot, const PathState &s)
+// (camera = the queue of bounce 0: every ray there has throughput 1 and radiance 0, so the `c` stream -- a quarter of the queue's bytes --
+// is neither written by generate_rays_kernel nor read by the kernels of bounce 0)
+__device__ __forceinline__ void store_ray(const RayQueue &q, uint32_t slot, const PathState &s, bool camera = false)
 {
     store_through(q.a + slot, s.o.x, s.o.y, s.o.z, s.d.x);
     store_through(q.b + slot, s.d.y, s.d.z, s.thr.x, s.thr.y);
-    store_through(q.c + slot, s.thr.z, s.rad.x, s.rad.y, s.rad.z);
+    if (!camera) store_through(q.c + slot, s.thr.z, s.rad.x, s.rad.y, s.rad.z);
     store_through(q.rng + slot, s.rng.x, s.rng.y, s.rng.z, s.rng.w);
     store_through(q.pixel + slot, s.pixel);
 }
-__device__ __forceinline__ PathState load_ray(const RayQueue &q, uint32_t slot)
+__device__ __forceinline__ PathState load_ray(const RayQueue &q, uint32_t slot, bool camera = false)
 {
     PathState s;
-    float4 a = q.a[slot], b = q.b[slot], c = q.c[slot];
+    float4 a = q.a[slot], b = q.b[slot], c = make_float4(1.0f, 0.0f, 0.0f, 0.0f);
+    if (!camera) c = q.c[slot];
     uint4 g = q.rng[slot];
     s.o = mk(a.x, a.y, a.z); s.d = mk(a.w, b.x, b.y); s.thr = mk(b.z, b.w, c.x); s.rad = mk(c.y, c.z, c.w);
     s.rng.x = g.x; s.rng.y = g.y; s.rng.z = g.z; s.rng.w = g.w;
@@ -194,7 +197,7 @@ __global__ void __launch_bounds__(256) generate_rays_kernel(FrameParams P, Image
     }
     s.thr = mk(1.0f, 1.0f, 1.0f); s.rad = mk(0.0f, 0.0f, 0.0f);
     s.pixel |= pixel_tag;
-    store_ray(wb.q[0], slot_off + idx, s);
+    store_ray(wb.q[0], slot_off + idx, s, true);
     if (wb.best[0]) store_through(wb.best[0] + (slot_off + idx), 0xFFFFFFFFFFFFFFFFull);
 }
 
@@ -398,7 +401,7 @@ __global__ void __launch_bounds__(256) bounce_kernel(SceneView sc, FrameParams P
         bool alive = false;
         PathState s;
         if (valid) {
-            s = load_ray(qin, slot);
+            s = load_ray(qin, slot, bounce == 0u);
             Hit h; h.t = kInf; h.material = 0; h.point = h.normal = mk(0.0f, 0.0f, 0.0f);
             const bool hit_sphere = sphere_pass(sc, s.o, s.d, h);                        // traverse (:433)
             const bool hit_mesh = hr.best_v[r] != 0xFFFFFFFFu;
@@ -721,7 +724,7 @@ __global__ void __launch_bounds__(256) shade_kernel(SceneView sc, FrameParams P,
     bool alive = false;
     PathState s;
     if (valid) {
-        s = load_ray(qin, slot);
+        s = load_ray(qin, slot, bounce == 0u);
         const unsigned long long key = best_in[slot];
         Hit h; h.t = kInf; h.material = 0; h.point = h.normal = mk(0.0f, 0.0f, 0.0f);
         const bool hit_sphere = sphere_pass(sc, s.o, s.d, h);                            // traverse (:433)
